@@ -251,6 +251,14 @@ class DINO(_Base):
                                        warmup_teacher_temp=mk.warmup_teacher_temperature, teacher_temp=mk.teacher_temperature,
                                        warmup_teacher_temp_epochs=mk.warmup_teacher_temperature_epochs, num_epochs=self.max_epochs)
         self.last_step = 0
+        # ---- validation pieces (base.py:277-296): online k-NN bank, per-batch metric list, SSL validation loss switch
+        self.knn_eval = cfg.knn_eval.enabled
+        self.knn_k = cfg.knn_eval.k
+        if self.knn_eval:
+            from ..utils.knn import WeightedKNNClassifier
+            self.knn = WeightedKNNClassifier(k=self.knn_k, distance_fx=cfg.knn_eval.distance_func)
+        self.validation_step_outputs: List[Dict[str, Any]] = []
+        self.compute_ssl_val_loss = cfg.ssl_val_loss
         self.batch_crops = True  # pack same-size crops into one ragged batch per network
         self.overlap_streams = True  # teacher / local-crop passes on side HIP streams (see training_step)
         self._streams = None
@@ -277,6 +285,11 @@ class DINO(_Base):
         cfg.scheduler.warmup_epochs = omegaconf_select(cfg, "scheduler.warmup_epochs", 10)
         cfg.scheduler.interval = omegaconf_select(cfg, "scheduler.interval", "step")
         cfg.mixed_channels = omegaconf_select(cfg, "mixed_channels", False)
+        cfg.ssl_val_loss = omegaconf_select(cfg, "ssl_val_loss", False)
+        ensure_node(cfg, "knn_eval")
+        cfg.knn_eval.enabled = omegaconf_select(cfg, "knn_eval.enabled", False)
+        cfg.knn_eval.k = omegaconf_select(cfg, "knn_eval.k", 20)
+        cfg.knn_eval.distance_func = omegaconf_select(cfg, "knn_eval.distance_func", "euclidean")
         cfg.momentum.base_tau = omegaconf_select(cfg, "momentum.base_tau", 0.99)
         cfg.momentum.final_tau = omegaconf_select(cfg, "momentum.final_tau", 1.0)
         cfg.momentum.classifier = omegaconf_select(cfg, "momentum.classifier", False)
@@ -429,6 +442,10 @@ class DINO(_Base):
                     feats_list += [self.backbone(x, nl + k, list_num_channels) for k, x in enumerate(small)]
             self._local_pending = use_streams
         self._last_outs = {"feats": feats_list, "z": p, "momentum_z": momentum_p}
+        if self.knn_eval:  # online k-NN bank: CLS features of the global crops with a label (base.py:723-731)
+            t_rep = targets.repeat(nl)
+            mask = t_rep != -1
+            self.knn.update(train_features=torch.cat(feats_list[:nl])[mask].detach(), train_targets=t_rep[mask])
         dino_loss = self.dino_loss_func(p, momentum_p)
         self.log("dino_loss_train", dino_loss, on_step=True, on_epoch=True, sync_dist=True)
         return dino_loss
@@ -465,6 +482,73 @@ class DINO(_Base):
             self.momentum_updater.update_tau(cur_step=self.trainer.global_step,
                                              max_steps=self.trainer.estimated_stepping_batches)
         self.last_step = self.trainer.global_step
+
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def validation_step(self, batch: Sequence[Any], batch_idx: int, dataloader_idx: int = None,
+                        update_validation_step_outputs: bool = True) -> Dict[str, Any]:
+        """Reference flow for mixed-channel batches: BaseMethod.validation_step (base.py:753-870), BaseMomentumMethod's
+        momentum pass on top (base.py:1278-1375), DINO's SSL validation loss (dino.py:327-365).
+          ssl_val_loss off: the batch is ONE tensor of collated channel images; student forward (feats / logits / z), teacher
+            forward (momentum feats / z, returned only through the k-NN / outs of the student as the reference does), metrics =
+            {"batch_size": len(targets)}.
+          ssl_val_loss on: the batch carries num_crops crops; student head pass on the large crops, backbone-only pass on the
+            small ones, teacher pass on the large crops, `dino_loss_val` = the training loss on them -- which also moves the
+            centre, exactly as calling `dino_loss_func` does in the reference (losses/dino.py:98).
+        With knn_eval (and not in Lightning's sanity check) the CLS features feed the online k-NN as test samples."""
+        X, targets, list_num_channels = batch
+        self.list_num_channels = list_num_channels
+        if isinstance(list_num_channels[0], int):
+            self.list_num_channels = list_num_channels = [list_num_channels]
+        sanity = bool(getattr(self.trainer, "sanity_checking", False)) if self.trainer is not None else False
+        nl = self.num_large_crops
+        if self.compute_ssl_val_loss:
+            X = [X] if isinstance(X, torch.Tensor) else X
+            assert len(X) == self.num_crops
+            batch_size = len(list_num_channels[0])
+            per = [self(x, k) for k, x in enumerate(X[:nl])]
+            outs: Dict[str, Any] = {k: [o[k] for o in per] for k in per[0]}
+            if self.multicrop:
+                for k, x in enumerate(X[nl:]):  # index restarts at 0 as in the reference (base.py:803-806)
+                    outs["feats"] = outs["feats"] + [self.multicrop_forward(x, k)["feats"]]
+            if self.knn_eval and not sanity:
+                # the reference hands the LIST of per-crop features to the k-NN here (base.py:814-818, `.detach()` on a list
+                # fails there); the usable reading -- global-crop features as test samples -- is what is built
+                self.knn.update(test_features=torch.cat(outs.pop("feats")[:nl]).detach(), test_targets=targets.repeat(nl).detach())
+            metrics = {"batch_size": batch_size}
+            outs.update(metrics)
+            mom = [self.momentum_forward(x, k) for k, x in enumerate(X[:nl])]
+            outs.update({"momentum_" + k: [o[k] for o in mom] for k in mom[0]})
+            dino_loss = self.dino_loss_func(torch.cat(outs["z"]), torch.cat(outs["momentum_z"]))
+            self.log("dino_loss_val", dino_loss, on_step=True, on_epoch=True, sync_dist=True)
+            if update_validation_step_outputs:
+                outs.update({"dino_loss_val": dino_loss})
+                self.validation_step_outputs.append(outs)
+            return outs
+        if not isinstance(X, torch.Tensor):
+            X = X[0]
+        outs = self(X, 0)
+        if self.knn_eval and not sanity:
+            self.knn.update(test_features=outs.pop("feats").detach(), test_targets=targets.detach())
+        metrics = {"batch_size": targets.size(0)}
+        outs.update(metrics)
+        self.momentum_forward(X, 0)  # executed and dropped by the reference when there is no momentum classifier
+        if update_validation_step_outputs:
+            self.validation_step_outputs.append(outs)
+        return outs
+
+    def on_validation_epoch_end(self):
+        """base.py:1377-1436 for mixed-channel runs: the class-probe metrics do not exist there (no labels-vs-logits pass), so
+        the epoch log holds the online k-NN accuracies only -- the reference computes them inside its `not mixed_channels`
+        branch and therefore never reports them on this path; reporting them is the one deliberate addition."""
+        log = {}
+        sanity = bool(getattr(self.trainer, "sanity_checking", False)) if self.trainer is not None else False
+        if self.knn_eval and not sanity:
+            acc1, acc5 = self.knn.compute()
+            log.update({"val_knn_acc1": acc1, "val_knn_acc5": acc5})
+        if len(log) > 0:
+            self.log_dict(log, sync_dist=True)
+        self.validation_step_outputs.clear()
 
     @torch.no_grad()
     def extract_features(self, batch):

@@ -364,6 +364,32 @@ def training_step(sd: Params, crops: List[torch.Tensor], num_channels: List[List
     return loss.detach(), grads, new_center, aux
 
 
+@torch.no_grad()
+def validation_step(sd: Params, crops: List[torch.Tensor], num_channels: List[List[int]], num_large_crops: int,
+                    teacher_temp: float, ssl_val_loss: bool, student_temp: float = 0.1, nheads: int = 2):
+    """DINO.validation_step for mixed-channel batches (dino.py:327-365 over base.py:753-870 and :1278-1375).
+    ssl_val_loss: student (backbone + probe + head) on the large crops, student backbone on the small ones, teacher on the
+    large crops, dino_loss_val on them and -- because the loss module updates it in forward (losses/dino.py:98) -- the moved
+    centre.  Otherwise `crops` is the single validation crop: student forward only, batch_size = number of images.
+    Returns a dict with feats / logits / z (lists per crop when ssl_val_loss), momentum_z, dino_loss_val, center, batch_size."""
+    bb, hd = split_prefix(sd, "backbone."), split_prefix(sd, "head.")
+    tbb, thd = split_prefix(sd, "momentum_backbone."), split_prefix(sd, "momentum_head.")
+    W, b = sd["classifier.weight"], sd["classifier.bias"]
+    if not ssl_val_loss:
+        x = crops[0] if isinstance(crops, (list, tuple)) else crops
+        f = backbone_ragged(bb, x, num_channels[0], nheads)
+        return {"feats": f, "logits": f @ W.t() + b, "z": head_forward(hd, f), "batch_size": len(num_channels[0]),
+                "center": sd["dino_loss_func.center"]}
+    feats = [backbone_ragged(bb, crops[k], num_channels[k], nheads) for k in range(len(crops))]
+    z = [head_forward(hd, f) for f in feats[:num_large_crops]]
+    tz = [head_forward(thd, backbone_ragged(tbb, crops[k], num_channels[k], nheads)) for k in range(num_large_crops)]
+    p_s, p_t = torch.cat(z), torch.cat(tz)
+    center = sd["dino_loss_func.center"]
+    return {"feats": feats, "logits": [f @ W.t() + b for f in feats[:num_large_crops]], "z": z, "momentum_z": tz,
+            "dino_loss_val": dino_loss(p_s, p_t, center, teacher_temp, student_temp), "center": center_update(center, p_t),
+            "batch_size": len(num_channels[0])}
+
+
 def adamw_step(param: torch.Tensor, grad: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step: int, lr: float,
                wd: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8):
     """torch.optim.AdamW single-tensor update (the optimiser the eval yamls name; base.py:67-72)."""

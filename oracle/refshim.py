@@ -196,7 +196,8 @@ def load_custom_transforms():
 
 def dino_cfg(embed_dim=192, num_prototypes=4096, num_large_crops=2, num_small_crops=0, max_epochs=10,
              proj_hidden_dim=2048, proj_output_dim=256, batch_size=4, lr=5e-4, weight_decay=1e-4,
-             base_tau=0.9995, final_tau=1.0, warmup_teacher_temperature_epochs=3, clip_grad=0, freeze_last_layer=1):
+             base_tau=0.9995, final_tau=1.0, warmup_teacher_temperature_epochs=3, clip_grad=0, freeze_last_layer=1,
+             ssl_val_loss=False, knn_eval=False, knn_k=20, knn_distance="euclidean"):
     """Minimal cfg for the reference `DINO(cfg)` (SURVEY.md section 8(c) key list)."""
     return _AttrDict({
         "method": "dino",
@@ -215,5 +216,6 @@ def dino_cfg(embed_dim=192, num_prototypes=4096, num_large_crops=2, num_small_cr
                           "num_prototypes": num_prototypes, "clip_grad": clip_grad,
                           "freeze_last_layer": freeze_last_layer,
                           "warmup_teacher_temperature_epochs": warmup_teacher_temperature_epochs},
-        "ssl_val_loss": False, "slurm": {"enabled": False}, "wandb": {"enabled": False},
+        "ssl_val_loss": ssl_val_loss, "slurm": {"enabled": False}, "wandb": {"enabled": False},
+        "knn_eval": {"enabled": knn_eval, "k": knn_k, "distance_func": knn_distance},
     })

@@ -291,7 +291,48 @@ def golden_jitter(name):
     print("wrote", name)
 
 
+def golden_val(name, D, PR, nch, sizes, n_large):
+    """DINO.validation_step (dino.py:327-365 over base.py:753-870, 1278-1375) on the unmodified reference, both settings of
+    cfg.ssl_val_loss: student feats / logits / z, teacher z, dino_loss_val and the centre it leaves behind."""
+    out = {"D": D, "P": PR, "nch": np.asarray(nch), "sizes": np.asarray(sizes), "n_large": n_large}
+    imgs = P.make_images(nch, sizes, seed=7)
+    batch = ref.one_channel_collate_fn([(i, c, l) for i, (c, l) in enumerate(imgs)])
+    for ssl in (True, False):
+        cfg = refshim.dino_cfg(embed_dim=D, num_prototypes=PR, num_large_crops=n_large, num_small_crops=len(sizes) - n_large,
+                               ssl_val_loss=ssl)
+        model = ref.DINO(cfg)
+        model.load_state_dict(build_sd(D, PR))
+        model.current_epoch = 1
+        model.on_train_epoch_start()
+        tag = "ssl" if ssl else "plain"
+        with torch.no_grad():
+            if ssl:
+                outs = model.validation_step(batch, 0)
+                out[f"{tag}::dino_loss_val"] = np.float64(outs["dino_loss_val"].item())
+                out[f"{tag}::z"] = f32(torch.cat(outs["z"]))[:, :64]
+                out[f"{tag}::momentum_z"] = f32(torch.cat(outs["momentum_z"]))[:, :64]
+                out[f"{tag}::feats"] = f32(torch.cat(outs["feats"][:n_large]))
+                out[f"{tag}::n_feats"] = len(outs["feats"])
+                out[f"{tag}::logits"] = f32(torch.cat(outs["logits"]))
+            else:
+                X, targets, ncl = batch
+                outs = model.validation_step((X[0], targets, [ncl[0]]), 0)
+                out[f"{tag}::z"] = f32(outs["z"])[:, :64]
+                out[f"{tag}::feats"] = f32(outs["feats"])
+                out[f"{tag}::logits"] = f32(outs["logits"])
+            out[f"{tag}::batch_size"] = int(outs["batch_size"])
+            out[f"{tag}::n_outputs"] = len(model.validation_step_outputs)
+            out[f"{tag}::center"] = f32(model.dino_loss_func.center)[0, :256]
+            model.on_validation_epoch_end()
+            assert len(model.validation_step_outputs) == 0
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, out["ssl::dino_loss_val"])
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "val":
+        golden_val("val_tiny", 192, 4096, [2, 1, 4], [224, 224, 96], 2)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "jitter":
         golden_jitter("jitter")
         sys.exit(0)
@@ -300,6 +341,17 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "lars":
         golden_lars("lars")
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "steps_r02":
+        # round 2: Small / Base training steps (the D = 384 / 768 backward kernels) and a >= 24576-token Tiny step
+        # (the row count at which ChAdaViT dispatches the whole-block kernel by default)
+        which = sys.argv[2:] or ["small", "base", "big"]
+        if "small" in which:
+            golden_step("step_small_mixed", 384, 4096, [2, 7, 1], [224, 224, 96, 96], 2, 1)
+        if "base" in which:
+            golden_step("step_base_c10", 768, 4096, [10, 3], [224, 224], 2, 1)
+        if "big" in which:
+            golden_step("step_tiny_fused_rows", 192, 4096, [10, 10, 10, 10, 10, 8, 5, 3, 1], [224, 224, 96, 96], 2, 1)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "attnmap":
         golden_attnmap("attnmap_tiny", 192, 2, 224, 51, 52)
