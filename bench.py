@@ -15,8 +15,9 @@ slower per image).  Inputs are resident in HBM before the timed region.
 Prints ONE JSON line on rank 0 (contract in the task statement) including
   "roofline"     -- dominant kernel (largest share of GPU time among the instrumented entry points),
                     timed live with HIP events on the launch stream during the timed steps;
-  "cpu_baseline" -- the CPU oracle (oracle/chada_ref.py, parity-pinned to the reference) timed on the
-                    host cores on a bounded sample of the same workload (rank 0, N = 1 only).
+  "cpu_baseline" -- the CPU oracle (oracle/chada_ref.py, parity-pinned to the reference) timed on the host cores on
+                    BASELINE.json configs[0] (the reference's own CPU-runnable case; BASELINE.md section 3 protocol: padded and
+                    ragged variants, 2 warm-up + 5 timed steps, median; rank 0, N = 1 only, after the GPU timed region).
 """
 from __future__ import annotations
 
@@ -57,7 +58,6 @@ def parse():
     ap.add_argument("--batch", type=int, default=0, help="images per GPU (0 = workload default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-launch-profile", action="store_true")
-    ap.add_argument("--cpu-sample-images", type=int, default=2)
     ap.add_argument("--serial", action="store_true", help="one HIP stream (no teacher/local/dW side streams): per-kernel "
                     "durations in a rocprofv3 trace are then stand-alone durations (profiles/README.md)")
     return ap.parse_args()
@@ -110,39 +110,72 @@ def make_cfg(wl):
     })
 
 
-def cpu_baseline(wl, n_images, threads):
-    """Oracle (CPU fp32 restatement, ragged form) on a bounded sample of the same workload."""
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or "unknown"
+
+
+def cpu_baseline(threads, warmup=2, timed=5):
+    """BASELINE.md section 3 / SURVEY.md 8(d): the CPU oracle (oracle/chada_ref.py, pinned to the reference by tests/golden) on
+    BASELINE.json configs[0] -- Tiny/16, 1-channel 224x224 randn-like images, batch 4, 2 global crops, head 2048/256/4096,
+    fp32, AdamW with persistent moments + EMA -- in the two variants the plan names:
+      padded = 10-channel zero padding + key mask, i.e. the arithmetic the reference itself executes (chada_vit.py:226-239);
+      ragged = padding-free, i.e. what the HIP path computes.
+    `warmup` untimed + `timed` timed steps each, median reported.  Runs AFTER the GPU timed region, on the host cores."""
+    import statistics
     import torch
     from oracle import chada_ref as R
     from oracle import procedural as P
     from tests.golden_util import build_sd
     torch.set_num_threads(threads)
-    nch = channel_list(wl["channels"], n_images, 0)
-    sizes = [224] * wl["n_global"] + [96] * wl["n_local"]
-    imgs = P.make_images(nch, sizes, seed=1)
+    wl = WORKLOADS["cfg1"]
+    B = 4
+    imgs = P.make_images([1] * B, [224] * wl["n_global"], seed=1)
     crops, _, ncl = R.collate(imgs)
     crops = crops if isinstance(crops, list) else [crops]
     ncl = ncl if isinstance(ncl[0], list) else [ncl]
-    sd = build_sd(wl["D"], wl["P"])
-    times = []
-    for it in range(3):
-        t0 = time.perf_counter()
-        loss, grads, newc, _ = R.training_step(sd, crops, ncl, wl["n_global"], 0.04)
-        # optimiser + EMA on the host, as part of the step
-        for n, g in grads.items():
-            if g is not None:
-                sd[n], _, _ = R.adamw_step(sd[n], g, torch.zeros_like(g), torch.zeros_like(g), 1, 1e-4, 1e-4)
-        for pre_s, pre_t in (("backbone.", "momentum_backbone."), ("head.", "momentum_head.")):
-            for k in list(sd):
-                if k.startswith(pre_s):
-                    tk = pre_t + k[len(pre_s):]
-                    sd[tk] = 0.9995 * sd[tk] + 0.0005 * sd[k]
-        times.append(time.perf_counter() - t0)
-    best = min(times[1:])
-    return {"value": n_images / best, "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": f"oracle/chada_ref.training_step (ragged fp32 torch-CPU restatement) + AdamW + EMA, {n_images} images of the "
-                      f"same workload ({wl['channels']} ch, {wl['n_global']}x224 + {wl['n_local']}x96 crops), best of 2 timed steps "
-                      f"after 1 warm-up, {best:.2f} s/step"}
+    res = {}
+    for variant in ("padded", "ragged"):
+        sd = build_sd(wl["D"], wl["P"])
+        mom = {}
+        times = []
+        for it in range(warmup + timed):
+            t0 = time.perf_counter()
+            loss, grads, newc, _ = R.training_step(sd, crops, ncl, wl["n_global"], 0.04, padded=(variant == "padded"))
+            sd["dino_loss_func.center"] = newc
+            for n, g in grads.items():  # AdamW (base.py:67-72) with its moments carried from step to step
+                if g is not None:
+                    m, v = mom.get(n, (None, None))
+                    if m is None:
+                        m, v = torch.zeros_like(g), torch.zeros_like(g)
+                    sd[n], m, v = R.adamw_step(sd[n], g, m, v, it + 1, 5e-4 * B / 256, 1e-4)
+                    mom[n] = (m, v)
+            for pre_s, pre_t in (("backbone.", "momentum_backbone."), ("head.", "momentum_head.")):  # EMA (momentum.py:63-74)
+                for k in list(sd):
+                    if k.startswith(pre_s):
+                        tk = pre_t + k[len(pre_s):]
+                        sd[tk] = 0.9995 * sd[tk] + 0.0005 * sd[k]
+            dt = time.perf_counter() - t0
+            if it >= warmup:
+                times.append(dt)
+        med = statistics.median(times)
+        res[variant] = {"value": round(B / med, 4), "unit": "images/s", "median_s_per_step": round(med, 4),
+                        "min_s_per_step": round(min(times), 4), "timed_steps": timed, "warmup_steps": warmup,
+                        "final_loss": round(float(loss), 4)}
+    sample = ("BASELINE.json configs[0]: ChAda-ViT-Tiny/16, 1-channel 224x224, batch 4, 2 global crops, head 2048/256/4096, fp32; "
+              "oracle/chada_ref.training_step + AdamW (persistent moments) + EMA; "
+              f"{warmup} warm-up + {timed} timed steps per variant, median; top-level value = the padded variant "
+              "(10-channel padding + key mask: the arithmetic the reference executes)")
+    return {"value": res["padded"]["value"], "unit": "images/s", "cores": threads, "kind": "port", "sample": sample,
+            "cpu_model": _cpu_model(), "host_logical_cpus": os.cpu_count(), "torch": torch.__version__,
+            "padded": res["padded"], "ragged": res["ragged"]}
 
 
 
@@ -460,7 +493,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             threads = min(os.cpu_count() or 1, 128)
             try:
-                out["cpu_baseline"] = cpu_baseline(wl, args.cpu_sample_images, threads)
+                out["cpu_baseline"] = cpu_baseline(threads)
             except Exception as e:  # noqa: BLE001 - the GPU number must still be reported
                 out["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": threads, "kind": "port", "sample": f"failed: {e!r}"}
         print(json.dumps(out), flush=True)

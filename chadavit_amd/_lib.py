@@ -21,11 +21,15 @@ class HipExtensionMissing(RuntimeError):
     pass
 
 
-def declared_symbols(header: str = HEADER):
-    """Every `int chadavit_*(` / `long long chadavit_*(` entry point declared in the public header."""
+def declared_prototypes(header: str = HEADER):
+    """{entry point: declared return type} for every `int chadavit_*(` / `long long chadavit_*(` in the public header."""
     with open(header) as f:
         src = f.read()
-    return sorted(set(re.findall(r"\b(?:int|long long)\s+(chadavit_\w+)\s*\(", src)))
+    return {name: ret for ret, name in re.findall(r"\b(int|long long)\s+(chadavit_\w+)\s*\(", src)}
+
+
+def declared_symbols(header: str = HEADER):
+    return sorted(declared_prototypes(header))
 
 
 _lib = None
@@ -39,9 +43,9 @@ def lib() -> ctypes.CDLL:
                 f"{LIB_PATH} not found: build it with `python -m chadavit_amd.build` (hipcc, gfx950). "
                 "chadavit_amd has no CPU fallback.")
         _lib = ctypes.CDLL(LIB_PATH)
-        for name in declared_symbols():
+        for name, ret in declared_prototypes().items():
             fn = getattr(_lib, name)  # AttributeError if the library does not export a declared symbol
-            fn.restype = ctypes.c_int
+            fn.restype = ctypes.c_longlong if ret == "long long" else ctypes.c_int  # as the header declares it
         if _lib.chadavit_abi_version() != ABI_VERSION:
             raise HipExtensionMissing(f"ABI mismatch: library {_lib.chadavit_abi_version()} != binding {ABI_VERSION}; rebuild")
     return _lib

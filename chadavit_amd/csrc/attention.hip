@@ -1343,7 +1343,7 @@ extern "C" int chadavit_attn_tile_rows(void) { return TILE; }
 
 extern "C" int chadavit_attn_fwd(const chada_bf16* qkv_, chada_bf16* out_, float* lse, const int* cu_seqlens,
                                  const int* work, int n_work, int T, int D, int H, void* stream) {
-  (void)hipGetLastError();  // drop stale sticky errors left by other HIP users (e.g. event queries)
+  CHADA_ENTRY();
   if (!qkv_ || !out_ || !lse || !cu_seqlens || !work || n_work <= 0 || n_work % 8 != 0 || T <= 0 || H <= 0 || D % H != 0) return 1;
   const int dh = D / H;
   const bf16_t* qkv = reinterpret_cast<const bf16_t*>(qkv_);
@@ -1381,7 +1381,7 @@ extern "C" int chadavit_attn_fwd(const chada_bf16* qkv_, chada_bf16* out_, float
 extern "C" int chadavit_attn_bwd_parts(const chada_bf16* qkv_, const chada_bf16* out_, const chada_bf16* dout_, const float* lse,
                                        chada_bf16* dqkv_, float* delta, const int* cu_seqlens, const int* work, int n_work,
                                        int T, int D, int H, int parts, void* stream) {
-  (void)hipGetLastError();
+  CHADA_ENTRY();
   if (!qkv_ || !out_ || !dout_ || !lse || !dqkv_ || !delta || !cu_seqlens || !work || n_work <= 0 || n_work % 8 != 0 || T <= 0 || H <= 0 ||
       D % H != 0 || D % 4 != 0)
     return 1;
@@ -1434,7 +1434,7 @@ extern "C" int chadavit_attn_bwd(const chada_bf16* qkv_, const chada_bf16* out_,
 
 extern "C" int chadavit_attn_probs(const chada_bf16* qkv_, float* probs, const int* cu_seqlens, const long long* prob_offsets,
                                    int B, int T, int D, int H, int max_len, void* stream) {
-  (void)hipGetLastError();
+  CHADA_ENTRY();
   if (!qkv_ || !probs || !cu_seqlens || !prob_offsets || B <= 0 || T <= 0 || H <= 0 || D % H != 0) return 1;
   const int dh = D / H;
   if (dh % 8 != 0 || dh > 384 || max_len > 64 * PROB_MAXK) return 2;

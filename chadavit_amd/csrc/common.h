@@ -18,6 +18,16 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 #define CHADA_LDS __attribute__((address_space(3)))
 
+// Entry check: a HIP error that is already pending when an entry point is called (an asynchronous fault of an earlier
+// launch, a failed launch of another library) is REPORTED as 1000 + hipError_t, not swallowed -- the caller would otherwise
+// see it attributed to a later, innocent call or never.  hipErrorNotReady is not a fault: it is what hipEventQuery /
+// hipStreamQuery leave behind when polled (PyTorch's caching allocator polls events all the time), so it alone is dropped.
+#define CHADA_ENTRY()                                                       \
+  do {                                                                      \
+    hipError_t e__ = hipGetLastError();                                     \
+    if (e__ != hipSuccess && e__ != hipErrorNotReady) return 1000 + (int)e__; \
+  } while (0)
+
 #define CHADA_CHECK_LAUNCH()                         \
   do {                                               \
     hipError_t e__ = hipGetLastError();              \

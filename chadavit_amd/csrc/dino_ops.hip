@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256) void knn_vote_kernel(const float* __restrict__
 extern "C" int chadavit_abi_version(void) { return 1; }
 
 extern "C" int chadavit_l2norm_fwd(const float* x, chada_bf16* y, float* inv_norm, int M, int N, void* stream) {
-  (void)hipGetLastError();  // drop stale sticky errors left by other HIP users (e.g. event queries)
+  CHADA_ENTRY();
   if (!x || !y || !inv_norm || M <= 0 || N <= 0) return 1;
   hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(grid_for((size_t)M * 64)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
                      reinterpret_cast<bf16_t*>(y), inv_norm, M, N);
@@ -413,7 +413,7 @@ extern "C" int chadavit_l2norm_fwd(const float* x, chada_bf16* y, float* inv_nor
 }
 extern "C" int chadavit_l2norm_bwd(const float* dy, const float* x, const float* inv_norm, chada_bf16* dx, int M, int N,
                                    void* stream) {
-  (void)hipGetLastError();  // drop stale sticky errors left by other HIP users (e.g. event queries)
+  CHADA_ENTRY();
   if (!dy || !x || !inv_norm || !dx || M <= 0 || N <= 0) return 1;
   hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(grid_for((size_t)M * 64)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dy,
                      x, inv_norm, reinterpret_cast<bf16_t*>(dx), M, N);
@@ -422,7 +422,7 @@ extern "C" int chadavit_l2norm_bwd(const float* dy, const float* x, const float*
 }
 extern "C" int chadavit_weightnorm_fwd(const float* v, const float* g, chada_bf16* w, chada_bf16* w_t, float* inv_norm, int P,
                                        int K, void* stream) {
-  (void)hipGetLastError();  // drop stale sticky errors left by other HIP users (e.g. event queries)
+  CHADA_ENTRY();
   if (!v || !g || !w || !inv_norm || P <= 0 || K <= 0) return 1;
   hipLaunchKernelGGL(weightnorm_fwd_kernel, dim3(grid_for((size_t)P * 64)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      v, g, reinterpret_cast<bf16_t*>(w), reinterpret_cast<bf16_t*>(w_t), inv_norm, P, K);
@@ -431,7 +431,7 @@ extern "C" int chadavit_weightnorm_fwd(const float* v, const float* g, chada_bf1
 }
 extern "C" int chadavit_weightnorm_bwd(const float* dw, const float* v, const float* g, const float* inv_norm, float* dv,
                                        int accumulate, int P, int K, void* stream) {
-  (void)hipGetLastError();  // drop stale sticky errors left by other HIP users (e.g. event queries)
+  CHADA_ENTRY();
   if (!dw || !v || !g || !inv_norm || !dv || P <= 0 || K <= 0) return 1;
   hipLaunchKernelGGL(weightnorm_bwd_kernel, dim3(grid_for((size_t)P * 64)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      dw, v, g, inv_norm, dv, accumulate, P, K);
@@ -442,7 +442,7 @@ extern "C" int chadavit_weightnorm_bwd(const float* dw, const float* v, const fl
 extern "C" int chadavit_dino_loss(const float* student, const float* teacher, const float* center, float student_temp,
                                   float teacher_temp, float* loss_rows, chada_bf16* dstudent, float* teacher_colsum, int B,
                                   int P, void* stream) {
-  (void)hipGetLastError();  // drop stale sticky errors left by other HIP users (e.g. event queries)
+  CHADA_ENTRY();
   if (!student || !teacher || !center || !loss_rows || B <= 0 || P <= 0 || student_temp <= 0.f || teacher_temp <= 0.f) return 1;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(dino_loss_kernel, dim3(B), dim3(256), 0, s, student, teacher, center, 1.0f / student_temp,
@@ -453,7 +453,7 @@ extern "C" int chadavit_dino_loss(const float* student, const float* teacher, co
   return 0;
 }
 extern "C" int chadavit_center_ema(float* center, const float* colsum, float inv_count, float momentum, int P, void* stream) {
-  (void)hipGetLastError();  // drop stale sticky errors left by other HIP users (e.g. event queries)
+  CHADA_ENTRY();
   if (!center || !colsum || P <= 0) return 1;
   hipLaunchKernelGGL(center_ema_kernel, dim3((P + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), center,
                      colsum, inv_count, momentum, P);
@@ -461,7 +461,7 @@ extern "C" int chadavit_center_ema(float* center, const float* colsum, float inv
   return 0;
 }
 extern "C" int chadavit_sum_rows_f32(const float* x, float* out, int rows, int cols, float scale, void* stream) {
-  (void)hipGetLastError();  // drop stale sticky errors left by other HIP users (e.g. event queries)
+  CHADA_ENTRY();
   if (!x || !out || rows <= 0 || cols <= 0) return 1;
   hipLaunchKernelGGL(sum_rows_kernel, dim3((cols + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, out, rows,
                      cols, scale);
@@ -470,7 +470,7 @@ extern "C" int chadavit_sum_rows_f32(const float* x, float* out, int rows, int c
 }
 
 extern "C" int chadavit_ema_update(float* teacher, const float* student, float tau, long long n, void* stream) {
-  (void)hipGetLastError();  // drop stale sticky errors left by other HIP users (e.g. event queries)
+  CHADA_ENTRY();
   if (!teacher || !student || n <= 0) return 1;
   if (((uintptr_t)teacher | (uintptr_t)student) & 15) return 2;
   hipLaunchKernelGGL(ema_kernel, dim3(grid_for((size_t)n / 4 + 1, 2048)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
@@ -481,7 +481,7 @@ extern "C" int chadavit_ema_update(float* teacher, const float* student, float t
 extern "C" int chadavit_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
                                    float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2, long long n,
                                    void* stream) {
-  (void)hipGetLastError();  // drop stale sticky errors left by other HIP users (e.g. event queries)
+  CHADA_ENTRY();
   if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || bias_corr1 <= 0.f || bias_corr2 <= 0.f) return 1;
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((size_t)n, 2048)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), param,
                      grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, bias_corr1, sqrtf(bias_corr2), (size_t)n);
@@ -489,7 +489,7 @@ extern "C" int chadavit_adamw_step(float* param, const float* grad, float* exp_a
   return 0;
 }
 extern "C" int chadavit_cast_bf16(const float* src, chada_bf16* dst, long long n, void* stream) {
-  (void)hipGetLastError();  // drop stale sticky errors left by other HIP users (e.g. event queries)
+  CHADA_ENTRY();
   if (!src || !dst || n <= 0) return 1;
   if (((uintptr_t)src & 15) || ((uintptr_t)dst & 7)) return 2;
   hipLaunchKernelGGL(cast_kernel, dim3(grid_for((size_t)n / 4 + 1, 2048)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
@@ -499,7 +499,7 @@ extern "C" int chadavit_cast_bf16(const float* src, chada_bf16* dst, long long n
 }
 extern "C" int chadavit_cast_transpose_bf16(const float* src, chada_bf16* dst, chada_bf16* dst_t, int rows, int cols,
                                             void* stream) {
-  (void)hipGetLastError();  // drop stale sticky errors left by other HIP users (e.g. event queries)
+  CHADA_ENTRY();
   if (!src || !dst_t || rows <= 0 || cols <= 0) return 1;
   hipLaunchKernelGGL(cast_transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), src, reinterpret_cast<bf16_t*>(dst), reinterpret_cast<bf16_t*>(dst_t),
@@ -509,7 +509,7 @@ extern "C" int chadavit_cast_transpose_bf16(const float* src, chada_bf16* dst, c
 }
 extern "C" int chadavit_cast_transpose_batched(const float* src, chada_bf16* dst_t, const long long* desc, int n_mats,
                                                int max_tiles, void* stream) {
-  (void)hipGetLastError();
+  CHADA_ENTRY();
   if (!src || !dst_t || !desc || n_mats <= 0 || max_tiles <= 0) return 1;
   hipLaunchKernelGGL(cast_transpose_batched_kernel, dim3(max_tiles < 256 ? max_tiles : 256, n_mats), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), src, reinterpret_cast<bf16_t*>(dst_t), desc);
@@ -518,7 +518,7 @@ extern "C" int chadavit_cast_transpose_batched(const float* src, chada_bf16* dst
 }
 extern "C" int chadavit_clip_tensors(float* grads, const long long* offsets, const long long* sizes, int n_tensors, float clip,
                                      void* stream) {
-  (void)hipGetLastError();  // drop stale sticky errors left by other HIP users (e.g. event queries)
+  CHADA_ENTRY();
   if (!grads || !offsets || !sizes || n_tensors <= 0 || clip <= 0.f) return 1;
   hipLaunchKernelGGL(clip_kernel, dim3(n_tensors), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), grads, offsets, sizes,
                      clip);
@@ -530,7 +530,7 @@ extern "C" int chadavit_lars_step(float* params, const float* grads, float* mome
                                   const long long* sizes, const int* flags, int n_tensors, float lr, float momentum,
                                   float dampening, float weight_decay, float eta, float eps, int clip_lr, int nesterov,
                                   void* stream) {
-  (void)hipGetLastError();
+  CHADA_ENTRY();
   if (!params || !grads || !momentum_bufs || !offsets || !sizes || !flags || n_tensors <= 0) return 1;
   if (nesterov && (momentum <= 0.f || dampening != 0.f)) return 1;
   hipLaunchKernelGGL(lars_kernel, dim3(n_tensors), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), params, grads,
@@ -542,7 +542,7 @@ extern "C" int chadavit_lars_step(float* params, const float* grads, float* mome
 extern "C" int chadavit_knn_vote(const float* sims, long long ld_sims, const int* train_targets, int n_test, int n_train, int k,
                                  float temperature, int use_exp, int num_classes, int top, int* top_classes, float* votes,
                                  void* stream) {
-  (void)hipGetLastError();
+  CHADA_ENTRY();
   if (!sims || !train_targets || !top_classes || n_test <= 0 || n_train <= 0 || k <= 0 || k > n_train || num_classes <= 0 ||
       top <= 0 || top > num_classes || ld_sims < n_train || (use_exp && temperature <= 0.f))
     return 1;

@@ -573,7 +573,7 @@ extern "C" long long chadavit_ffn_packed_bytes(int D, int FF) {
 }
 
 extern "C" int chadavit_ffn_pack(const chada_bf16* W1, const chada_bf16* W2, void* packed, int D, int FF, void* stream) {
-  (void)hipGetLastError();
+  CHADA_ENTRY();
   if (!W1 || !W2 || !packed) return 1;
   if (D != FD || FF < 2 * HC || FF > MAX_FF || FF % (2 * HC) != 0) return 2;
   hipLaunchKernelGGL(ffn_pack_kernel, dim3(FF / HC + 1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
@@ -634,7 +634,7 @@ extern "C" long long chadavit_ffn_proj_packed_bytes(int D, int FF) {  // always 
 
 extern "C" int chadavit_ffn_pack_proj_batched(const chada_bf16* slab, void* packed, const long long* desc, int n_layers, int D, int FF,
                                               void* stream) {
-  (void)hipGetLastError();
+  CHADA_ENTRY();
   if (!slab || !packed || !desc || n_layers <= 0) return 1;
   if (D != FD || FF < 2 * HC || FF > MAX_FF || FF % (2 * HC) != 0) return 2;
   hipLaunchKernelGGL(ffn_pack_proj_batched_kernel, dim3(FF / HC + 1 + 3 + 9, n_layers), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
@@ -645,7 +645,7 @@ extern "C" int chadavit_ffn_pack_proj_batched(const chada_bf16* slab, void* pack
 
 extern "C" int chadavit_ffn_pack_batched(const chada_bf16* slab, void* packed, const long long* desc, int n_layers, int D, int FF,
                                          void* stream) {
-  (void)hipGetLastError();
+  CHADA_ENTRY();
   if (!slab || !packed || !desc || n_layers <= 0) return 1;
   if (D != FD || FF < 2 * HC || FF > MAX_FF || FF % (2 * HC) != 0) return 2;
   hipLaunchKernelGGL(ffn_pack_batched_kernel, dim3(FF / HC + 1, n_layers), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
@@ -690,7 +690,7 @@ int launch_ffn(const chada_bf16* X, int ldx, const void* packed, const float* b1
 extern "C" int chadavit_ffn_fwd(const chada_bf16* X, int ldx, const void* packed, const float* b1, const float* b2,
                                 const chada_bf16* resid, int ldr, chada_bf16* Out, int ldo, chada_bf16* H, int ldh, int M, int D, int FF,
                                 int rows_per_wave, void* stream) {
-  (void)hipGetLastError();
+  CHADA_ENTRY();
   FfnLnTail ln{};
   return launch_ffn(X, ldx, packed, b1, b2, resid, ldr, Out, ldo, H, ldh, M, D, FF, rows_per_wave, ln, stream);
 }
@@ -700,7 +700,7 @@ extern "C" int chadavit_ffn_ln_fwd(const chada_bf16* X, int ldx, const void* pac
                                    const float* gamma_a, const float* beta_a, float eps_a, chada_bf16* X2, float* mean_a, float* rstd_a,
                                    const float* gamma_b, const float* beta_b, float eps_b, chada_bf16* Hn, float* mean_b, float* rstd_b,
                                    int M, int D, int FF, void* stream) {
-  (void)hipGetLastError();
+  CHADA_ENTRY();
   if (!gamma_a || !beta_a || !X2 || (mean_a == nullptr) != (rstd_a == nullptr) || (mean_b == nullptr) != (rstd_b == nullptr)) return 1;
   if (Hn && (!gamma_b || !beta_b)) return 1;
   FfnLnTail ln{};
@@ -739,7 +739,7 @@ extern "C" int chadavit_block_fwd(const chada_bf16* A, int lda, const chada_bf16
                                   int ldh, const float* gamma_a, const float* beta_a, float eps_a, chada_bf16* X2, float* mean_a,
                                   float* rstd_a, const float* gamma_b, const float* beta_b, float eps_b, chada_bf16* Hn, float* mean_b,
                                   float* rstd_b, chada_bf16* QKV, int ldqkv, const float* bqkv, int M, int D, int FF, void* stream) {
-  (void)hipGetLastError();
+  CHADA_ENTRY();
   if (QKV && (!gamma_b || !beta_b || !bqkv || ldqkv % 8 != 0)) return 1;
   if (!A || !Xres || !bo || !gamma1 || !beta1 || (mean1 == nullptr) != (rstd1 == nullptr)) return 1;
   if (!gamma_a || !beta_a || !X2 || (mean_a == nullptr) != (rstd_a == nullptr) || (mean_b == nullptr) != (rstd_b == nullptr)) return 1;

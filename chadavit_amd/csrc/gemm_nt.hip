@@ -549,7 +549,7 @@ int launch_nt(const NtArgs& a, hipStream_t s) {
 extern "C" int chadavit_gemm_nt(const chada_bf16* X, int ldx, const chada_bf16* W, int ldw, void* Out, int ldo, int M,
                                 int N, int K, const float* bias, int epilogue, const chada_bf16* aux, int ldaux,
                                 chada_bf16* aux_out, int out_fp32, void* stream) {
-  (void)hipGetLastError();  // drop stale sticky errors left by other HIP users (e.g. event queries)
+  CHADA_ENTRY();
   if (!X || !W || !Out || M <= 0 || N <= 0 || K <= 0) return 1;
   if (K % BK != 0 || N % 64 != 0 || ldx % 8 != 0 || ldw % 8 != 0 || ldo % 8 != 0) return 2;
   if ((epilogue == EPI_RESID || epilogue == EPI_RELUMASK || epilogue == EPI_GELUBWD) && (!aux || ldaux % 8 != 0)) return 1;
@@ -581,7 +581,7 @@ extern "C" int chadavit_gemm_nt(const chada_bf16* X, int ldx, const chada_bf16* 
 extern "C" int chadavit_tokenizer_gemm(const chada_bf16* patches, const chada_bf16* Wp, const float* bias,
                                        const float* pos, const float* chan, const int* chan_img, const int* chan_idx,
                                        chada_bf16* tokens, int Mp, int D, int K, int p, void* stream) {
-  (void)hipGetLastError();  // drop stale sticky errors left by other HIP users (e.g. event queries)
+  CHADA_ENTRY();
   if (!patches || !Wp || !pos || !chan_img || !chan_idx || !tokens || Mp <= 0 || p <= 0) return 1;
   if (K % BK != 0 || D % 64 != 0) return 2;
   NtArgs a{};

@@ -247,7 +247,7 @@ void launch_tn(const bf16_t* A, int lda, const bf16_t* B, int ldb, float* part, 
 extern "C" int chadavit_gemm_tn(const chada_bf16* A_, int lda, const chada_bf16* B_, int ldb, float* C, int ldc,
                                 float* colsumA, int T, int I, int J, int accumulate, float* workspace,
                                 long long workspace_floats, void* stream) {
-  (void)hipGetLastError();  // drop stale sticky errors left by other HIP users (e.g. event queries)
+  CHADA_ENTRY();
   if (!A_ || !B_ || !C || !workspace || T <= 0 || I <= 0 || J <= 0) return 1;
   if (I % 64 != 0 || J % 64 != 0 || lda % 8 != 0 || ldb % 8 != 0 || ldc % 4 != 0) return 2;
   const bf16_t* A = reinterpret_cast<const bf16_t*>(A_);

@@ -470,7 +470,7 @@ extern "C" int chadavit_layernorm_bwd_partials(void) { return LN_BWD_PARTIALS; }
 
 extern "C" int chadavit_layernorm_fwd(const chada_bf16* x, const float* gamma, const float* beta, chada_bf16* y,
                                       float* mean, float* rstd, int T, int D, float eps, void* stream) {
-  (void)hipGetLastError();  // drop stale sticky errors left by other HIP users (e.g. event queries)
+  CHADA_ENTRY();
   if (!x || !gamma || !beta || !y || T <= 0) return 1;
   if (D % 4 != 0 || D > 1024 || D <= 0) return 2;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -502,7 +502,7 @@ extern "C" int chadavit_layernorm_fwd(const chada_bf16* x, const float* gamma, c
 extern "C" int chadavit_layernorm_bwd(const chada_bf16* dy, const chada_bf16* x, const float* mean, const float* rstd,
                                       const float* gamma, const chada_bf16* dres, chada_bf16* dx, float* dgamma,
                                       float* dbeta, int accumulate, int T, int D, float* workspace, void* stream) {
-  (void)hipGetLastError();  // drop stale sticky errors left by other HIP users (e.g. event queries)
+  CHADA_ENTRY();
   if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || !workspace || T <= 0) return 1;
   if (D % 4 != 0 || D > 1024 || D <= 0) return 2;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -541,7 +541,7 @@ extern "C" int chadavit_layernorm_bwd(const chada_bf16* dy, const chada_bf16* x,
 extern "C" int chadavit_layernorm_fwd2(const chada_bf16* x, const float* gamma_a, const float* beta_a, const float* gamma_b,
                                        const float* beta_b, chada_bf16* y1, chada_bf16* y2, float* mean1, float* rstd1,
                                        float* mean2, float* rstd2, int T, int D, float eps_a, float eps_b, void* stream) {
-  (void)hipGetLastError();
+  CHADA_ENTRY();
   if (!x || !gamma_a || !beta_a || !gamma_b || !beta_b || !y1 || !y2 || T <= 0) return 1;
   if ((mean1 == nullptr) != (rstd1 == nullptr) || (mean2 == nullptr) != (rstd2 == nullptr)) return 1;
   if (D % 4 != 0 || D > 1024 || D <= 0) return 2;

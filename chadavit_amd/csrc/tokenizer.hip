@@ -134,7 +134,7 @@ inline int grid_for(size_t n, int cap = 4096) {
 }  // namespace
 
 extern "C" int chadavit_im2col(const float* x, chada_bf16* patches, int n_chan, int S, int patch, void* stream) {
-  (void)hipGetLastError();  // drop stale sticky errors left by other HIP users (e.g. event queries)
+  CHADA_ENTRY();
   if (!x || !patches || n_chan <= 0 || S <= 0) return 1;
   if (patch % 8 != 0 || S % patch != 0) return 2;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -147,7 +147,7 @@ extern "C" int chadavit_im2col(const float* x, chada_bf16* patches, int n_chan, 
 
 extern "C" int chadavit_write_cls(chada_bf16* tokens, const int* cu_seqlens, const float* cls, const float* pos0, int B, int D,
                                   void* stream) {
-  (void)hipGetLastError();  // drop stale sticky errors left by other HIP users (e.g. event queries)
+  CHADA_ENTRY();
   if (!tokens || !cu_seqlens || !cls || !pos0 || B <= 0 || D <= 0) return 1;
   hipLaunchKernelGGL(write_cls_kernel, dim3(grid_for((size_t)B * D)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      reinterpret_cast<bf16_t*>(tokens), cu_seqlens, cls, pos0, B, D);
@@ -156,7 +156,7 @@ extern "C" int chadavit_write_cls(chada_bf16* tokens, const int* cu_seqlens, con
 }
 
 extern "C" int chadavit_gather_rows(const chada_bf16* src, const int* rows, chada_bf16* dst, int n_rows, int D, void* stream) {
-  (void)hipGetLastError();  // drop stale sticky errors left by other HIP users (e.g. event queries)
+  CHADA_ENTRY();
   if (!src || !rows || !dst || n_rows <= 0 || D <= 0) return 1;
   if (D % 4 != 0) return 2;
   hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((size_t)n_rows * D / 4)), dim3(256), 0,
@@ -168,7 +168,7 @@ extern "C" int chadavit_gather_rows(const chada_bf16* src, const int* rows, chad
 
 extern "C" int chadavit_scatter_rows_zero(const chada_bf16* src, const int* rows, chada_bf16* dst, int n_rows, int T, int D,
                                           void* stream) {
-  (void)hipGetLastError();  // drop stale sticky errors left by other HIP users (e.g. event queries)
+  CHADA_ENTRY();
   if (!src || !rows || !dst || n_rows <= 0 || T <= 0 || D <= 0) return 1;
   if (D % 8 != 0) return 2;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -183,7 +183,7 @@ extern "C" int chadavit_scatter_rows_zero(const chada_bf16* src, const int* rows
 extern "C" int chadavit_tokenizer_bwd(const chada_bf16* dtok_, const int* cu_seqlens, const int* chan_img, const int* chan_idx,
                                       chada_bf16* dpatch_tok, float* dpos, float* dchan, float* dcls, float* workspace,
                                       int B, int n_chan, int p, int D, int max_channels, void* stream) {
-  (void)hipGetLastError();  // drop stale sticky errors left by other HIP users (e.g. event queries)
+  CHADA_ENTRY();
   if (!dtok_ || !cu_seqlens || !chan_img || !chan_idx || !dpatch_tok || !dpos || !dchan || !dcls || !workspace) return 1;
   if (B <= 0 || n_chan <= 0 || p <= 0 || D % 8 != 0 || max_channels <= 0) return 2;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void channel_jitter_kernel(float* __restrict__
 
 extern "C" int chadavit_channel_jitter(float* x, const float* shift, const float* gamma, const unsigned char* flip,
                                        int n_channel_images, int S, void* stream) {
-  (void)hipGetLastError();
+  CHADA_ENTRY();
   if (!x || !shift || !gamma || n_channel_images <= 0 || S <= 0) return 1;
   const long long rows = (long long)n_channel_images * S;
   const int grid = (int)(rows < 65536 ? rows : 65536);

@@ -147,7 +147,6 @@ def gemm_tn(a, b, c, colsum=None, accumulate=False, workspace=None, t_rows=None)
 
 
 def ffn_packed_bytes(D, FF):
-    lib().chadavit_ffn_packed_bytes.restype = ctypes.c_longlong
     return int(lib().chadavit_ffn_packed_bytes(c_int(D), c_int(FF)))
 
 
@@ -224,7 +223,6 @@ def ffn_ln_fwd(x, packed, b1, b2, ln_a, resid=None, z=None, h=None, ln_b=None, s
 
 
 def ffn_proj_packed_bytes(D, FF):
-    lib().chadavit_ffn_proj_packed_bytes.restype = ctypes.c_longlong
     return int(lib().chadavit_ffn_proj_packed_bytes(c_int(D), c_int(FF)))
 
 

@@ -69,8 +69,9 @@ def _run(world):
         cmd = [sys.executable, "-c", WORKER]
     else:
         env.update(CHADAVIT_DIST_BACKEND="gloo", CHADAVIT_SINGLE_DEVICE="1")
-        path = os.path.join(ROOT, "gpurun_out", "_ddp_worker.py")
-        os.makedirs(os.path.dirname(path), exist_ok=True)
+        import tempfile
+        tmpdir = tempfile.mkdtemp(prefix="chadavit_ddp_")  # scratch, never the repo tree
+        path = os.path.join(tmpdir, "_ddp_worker.py")
         with open(path, "w") as f:
             f.write(WORKER)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
