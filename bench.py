@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=0, help="images per GPU (0 = workload default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-launch-profile", action="store_true")
+    ap.add_argument("--verify-equal-batch", action="store_true", help="N > 1 self-check before the timed region: loss and "
+                    "gradient norm of the N-rank data-parallel step vs the same GLOBAL batch run by one rank alone (rel <= 3e-2)")
     ap.add_argument("--serial", action="store_true", help="one HIP stream (no teacher/local/dW side streams): per-kernel "
                     "durations in a rocprofv3 trace are then stand-alone durations (profiles/README.md)")
     return ap.parse_args()
@@ -134,13 +136,24 @@ def cpu_baseline(threads, warmup=2, timed=5):
     from oracle import chada_ref as R
     from oracle import procedural as P
     from tests.golden_util import build_sd
-    torch.set_num_threads(threads)
     wl = WORKLOADS["cfg1"]
     B = 4
     imgs = P.make_images([1] * B, [224] * wl["n_global"], seed=1)
     crops, _, ncl = R.collate(imgs)
     crops = crops if isinstance(crops, list) else [crops]
     ncl = ncl if isinstance(ncl[0], list) else [ncl]
+    # thread count: all logical CPUs is NOT the fastest setting for this batch-4 model on a 2 x 64-core host (measured: 128
+    # threads 3.9 s/step ragged vs 0.5 s on 8 threads of a slower CPU) -- take the best of a short sweep on the ragged step
+    sweep = {}
+    sd0 = build_sd(wl["D"], wl["P"])
+    for t in [c for c in (8, 16, 32, 64, 128) if c <= max(threads, 8)]:
+        torch.set_num_threads(t)
+        R.training_step(sd0, crops, ncl, wl["n_global"], 0.04)
+        t0 = time.perf_counter()
+        R.training_step(sd0, crops, ncl, wl["n_global"], 0.04)
+        sweep[t] = round(time.perf_counter() - t0, 4)
+    threads = min(sweep, key=sweep.get)
+    torch.set_num_threads(threads)
     res = {}
     for variant in ("padded", "ragged"):
         sd = build_sd(wl["D"], wl["P"])
@@ -175,8 +188,66 @@ def cpu_baseline(threads, warmup=2, timed=5):
               "(10-channel padding + key mask: the arithmetic the reference executes)")
     return {"value": res["padded"]["value"], "unit": "images/s", "cores": threads, "kind": "port", "sample": sample,
             "cpu_model": _cpu_model(), "host_logical_cpus": os.cpu_count(), "torch": torch.__version__,
+            "thread_sweep_s_per_ragged_step": sweep,
             "padded": res["padded"], "ragged": res["ragged"]}
 
+
+
+def verify_equal_batch(model, gs, wl, rank, world, dev, per_rank=4):
+    """Self-check of the data-parallel path on real hardware (the first N-GPU run has no other witness): one GLOBAL batch of
+    per_rank * world images is (a) run whole by every rank alone, gradient hooks off, and (b) run sharded -- rank r takes images
+    [r * per_rank, (r+1) * per_rank) -- with the gradient spans averaged over RCCL.  DDP semantics (losses/dino.py: each rank's
+    loss is its local mean, gradients are averaged) make mean-over-ranks(loss_b) == loss_a and grad_b == grad_a; compared by
+    loss and global gradient norm, rel <= 3e-2 (bf16 activations; different row counts pick different kernel dispatches)."""
+    import torch
+    import torch.distributed as dist
+    G = per_rank * world
+    nch_g = channel_list(wl["channels"], G, seed=77)
+    gen = torch.Generator(device=dev).manual_seed(4321)   # same seed on every rank: identical global batch everywhere
+    sizes = [224] * wl["n_global"] + [96] * wl["n_local"]
+    chan_off = [0]
+    for c in nch_g:
+        chan_off.append(chan_off[-1] + c)
+    crops_g = [torch.randn((chan_off[-1], 1, s_, s_), device=dev, generator=gen) for s_ in sizes]
+
+    def make(lo, hi):
+        cs = [c[chan_off[lo]:chan_off[hi]].contiguous() for c in crops_g]
+        return (cs if len(cs) > 1 else cs[0], torch.zeros(hi - lo, dtype=torch.int64, device=dev), [list(nch_g[lo:hi]) for _ in sizes])
+
+    center0 = model.dino_loss_func.center.clone()
+    hooks = (model.backbone.grad_ready_hook, model.head.grad_ready_hook)
+
+    def run(batch, synced):
+        model.dino_loss_func.center.copy_(center0)
+        model.backbone.grad_ready_hook, model.head.grad_ready_hook = hooks if synced else (None, None)
+        for p in model.parameters():
+            p.grad = None
+        loss = model.training_step(batch, 0)
+        if synced:
+            gs.begin_backward()
+        loss.backward()
+        if synced:
+            gs.finish()
+        model.on_after_backward()
+        sq = sum(float(p.grad.double().pow(2).sum()) for n, p in model.named_parameters()
+                 if p.grad is not None and n.startswith(("backbone.", "head.")))
+        return float(loss.item()), sq ** 0.5
+
+    model.current_epoch = 1   # past the prototype freeze: the head's last layer takes part
+    model.on_train_epoch_start()
+    loss_a, gn_a = run(make(0, G), False)
+    loss_b, gn_b = run(make(rank * per_rank, (rank + 1) * per_rank), True)
+    t = torch.tensor([loss_b], device=dev, dtype=torch.float64)
+    dist.all_reduce(t)
+    loss_b = float(t.item()) / world
+    model.backbone.grad_ready_hook, model.head.grad_ready_hook = hooks
+    model.dino_loss_func.center.copy_(center0)
+    for p in model.parameters():
+        p.grad = None
+    model.current_epoch = 0
+    rl, rg = abs(loss_a - loss_b) / abs(loss_a), abs(gn_a - gn_b) / gn_a
+    return {"global_batch": G, "loss_single": round(loss_a, 5), "loss_dp_mean": round(loss_b, 5), "gradnorm_single": gn_a,
+            "gradnorm_dp": gn_b, "rel_loss": rl, "rel_gradnorm": rg, "tolerance": 3e-2, "ok": bool(rl <= 3e-2 and rg <= 3e-2)}
 
 
 def replay_launches(counts, nch, wl, dev, reps=10):
@@ -245,7 +316,7 @@ def replay_launches(counts, nch, wl, dev, reps=10):
             fn = lambda: ops.ffn_ln_fwd(x, pk, b1_, b2_, (gg, bb_, 1e-5), resid=x, z=zz, h=hh, ln_b=(gg, bb_, 1e-5) if two else None,
                                         stats_a=sa, stats_b=sa if two else None)
         elif name == "proj_ffn_ln_fwd":
-            _, M, D_, FF_, wh, two, fq = key
+            _, M, D_, FF_, wh, two, fq, wb = key
             a_ = torch.randn((M, D_), device=dev).to(bf)
             xr_ = torch.randn((M, D_), device=dev).to(bf)
             w1 = (torch.randn((FF_, D_), device=dev) / D_ ** 0.5).to(bf)
@@ -266,9 +337,24 @@ def replay_launches(counts, nch, wl, dev, reps=10):
             yy = torch.empty((M, D_), device=dev, dtype=bf) if wh else None
             x1_ = torch.empty((M, D_), device=dev, dtype=bf)
             sa = (torch.empty(M, device=dev), torch.empty(M, device=dev)) if wh else None
-            fn = lambda: ops.proj_ffn_ln_fwd(a_, xr_, pkp, bo_, (gg, bb_, 1e-5), b1_, b2_, (gg, bb_, 1e-5), y=yy, x1=x1_ if wh else None, want_x1=wh, stats1=sa, z=zz, h=hh,
+            save_ = wh or wb
+            yy = torch.empty((M, D_), device=dev, dtype=bf) if save_ else None
+            zz = torch.empty((M, D_), device=dev, dtype=bf) if save_ else None
+            sa = (torch.empty(M, device=dev), torch.empty(M, device=dev)) if save_ else None
+            rb_ = ops.relu_bits_buffer(M, FF_, dev) if wb else None
+            fn = lambda: ops.proj_ffn_ln_fwd(a_, xr_, pkp, bo_, (gg, bb_, 1e-5), b1_, b2_, (gg, bb_, 1e-5), y=yy, x1=x1_ if save_ else None, want_x1=save_, stats1=sa, z=zz, h=hh,
                                              ln_b=(gg, bb_, 1e-5) if two else None, stats_a=sa, stats_b=sa if two else None,
-                                             qkv_bias=bq_ if fq else None, qkv=qq, want_hn=wh)
+                                             qkv_bias=bq_ if fq else None, qkv=qq, want_hn=save_, relu_bits=rb_)
+        elif name == "ffn_bwd_dx":
+            _, M, D_, FF_, wd = key
+            dz_ = torch.randn((M, D_), device=dev).to(bf)
+            w1t = (torch.randn((D_, FF_), device=dev) / D_ ** 0.5).to(bf)
+            w2t = (torch.randn((FF_, D_), device=dev) / FF_ ** 0.5).to(bf)
+            pkb = ops.ffn_pack(w2t, w1t)
+            rb_ = torch.randint(0, 256, (int(ops.relu_bits_buffer(M, FF_, dev).numel()),), device=dev, dtype=torch.uint8)
+            dx_ = torch.empty((M, D_), device=dev, dtype=bf)
+            dp_ = torch.empty((M, FF_), device=dev, dtype=bf) if wd else None
+            fn = lambda: ops.ffn_bwd_dx(dz_, pkb, rb_, dx1=dx_, dpre=dp_)
         elif name == "gemm_tn":
             _, T, I, J = key
             a = torch.randn((T, I), device=dev).to(bf)
@@ -345,7 +431,18 @@ def main():
         model.backbone.dw_side_stream = False
 
     # ---- synthetic batch, resident in HBM (randn crops, A1 collate layout)
-    nch = channel_list(wl["channels"], B, seed=1000 + rank)
+    # Mixed-channel workloads: ONE global batch of B * world images (same seed on every rank) is split with the token-balanced
+    # partition of data/sampler.py -- equal image counts per rank, balanced N + N^2 cost -- instead of an independent draw per
+    # rank, whose 17x per-image cost spread would make every step wait for the unluckiest rank.
+    tokens_per_rank = None
+    if "-" in wl["channels"]:
+        from chadavit_amd.data.sampler import balanced_partition, image_cost
+        nch_global = channel_list(wl["channels"], B * world, seed=1000)
+        parts = balanced_partition([image_cost(c) for c in nch_global], world)
+        nch = [nch_global[i] for i in parts[rank]]
+        tokens_per_rank = [sum(1 + nch_global[i] * 196 for i in parts[r]) * wl["n_global"] for r in range(world)]
+    else:
+        nch = channel_list(wl["channels"], B, seed=1000 + rank)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     sizes = [224] * wl["n_global"] + [96] * wl["n_local"]
     crops = [torch.randn((sum(nch), 1, s, s), device=dev, generator=gen) for s in sizes]
@@ -361,6 +458,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    verify = None
+    if args.verify_equal_batch and world > 1:
+        verify = verify_equal_batch(model, gs, wl, rank, world, dev)
     for i in range(args.warmup):
         tr.train_step(batch, i)
     barrier()
@@ -440,6 +540,8 @@ def main():
                 flops, bound = 2.0 * key[1] * key[2] * key[3], "mfma"
             elif name in ("ffn_fwd", "ffn_ln_fwd"):
                 flops, bound = 4.0 * key[1] * key[2] * key[3], "mfma"
+            elif name == "ffn_bwd_dx":  # dH = dz W2 and dx1 += dH W1
+                flops, bound = 4.0 * key[1] * key[2] * key[3], "mfma"
             elif name == "proj_ffn_ln_fwd":  # + the D x D projection (+ the next block's D x 3D QKV projection)
                 flops, bound = 4.0 * key[1] * key[2] * key[3] + 2.0 * key[1] * key[2] * key[2] * (4 if key[6] else 1), "mfma"
             elif name == "attn_fwd":
@@ -490,6 +592,19 @@ def main():
             out["launch_profile_top"] = [{"kernel": "/".join(str(x) for x in k), "ms_per_step": round(v["total_ms"], 3),
                                           "avg_us": round(v["avg_us"], 1), "launches_per_step": v["launches"]} for k, v in top]
         out["roofline"] = roof
+        if tokens_per_rank is not None:
+            out["config"]["tokens_per_rank"] = tokens_per_rank
+            out["config"]["tokens_per_rank_spread"] = round(max(tokens_per_rank) / min(tokens_per_rank) - 1.0, 4)
+        # the data-path collectives of one step: gradient spans averaged on the communication stream while the
+        # backward continues, + the P-float centre column sum
+        red = gs.reducer if gs is not None else None
+        out["rccl"] = {"backend": dist.get_backend() if world > 1 else None, "world": world,
+                       "spans": len(red.spans) if red is not None else 0,
+                       "bytes_per_step": (red.bytes if red is not None else 0) + (4 * wl["P"] if world > 1 else 0),
+                       "grad_op": "all_reduce(AVG) per block span on a side stream, overlapped with backward" if world > 1 else None,
+                       "center_op": "all_reduce(SUM) of the teacher-logit column sum" if world > 1 else None}
+        if verify is not None:
+            out["verify_equal_batch"] = verify
         if world == 1 and not args.no_cpu_baseline:
             threads = min(os.cpu_count() or 1, 128)
             try:

@@ -14,7 +14,7 @@ import torch  # noqa: F401  -- MUST precede the CDLL below: both link libamdhip6
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libchadavit_hip.so")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "chadavit_hip.h")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class HipExtensionMissing(RuntimeError):

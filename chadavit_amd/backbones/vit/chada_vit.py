@@ -286,7 +286,7 @@ def _block_fwd(m: ChAdaViT, flat: FlatParams, i: int, x, rb: RaggedBatch, save: 
                         epilogue=ops.EPI_RESID, aux=x)
         x1 = ops.layernorm_fwd(y, g1, b1, eps, mean=st[2] if save else None, rstd=st[3] if save else None)
     last = i + 1 >= len(m.blocks)
-    h_next = st_next = qkv_next = None
+    h_next = st_next = qkv_next = rbits = None
     ln2 = (flat.f(b + "norm2.weight"), flat.f(b + "norm2.bias"), m.blocks[i].norm2.eps)
     if not last:
         nb = f"blocks.{i + 1}."
@@ -299,11 +299,13 @@ def _block_fwd(m: ChAdaViT, flat: FlatParams, i: int, x, rb: RaggedBatch, save: 
         z = torch.empty((T, x.shape[1]), device=dev, dtype=torch.bfloat16) if save else None
         y = torch.empty((T, x.shape[1]), device=dev, dtype=torch.bfloat16) if save else None
         fuse_q = (not last) and flat.packed_has_next_qkv(b + "linear1.weight")
+        # the ReLU pattern of the hidden activation (1 bit per element) for the fused backward dX pass
+        rbits = ops.relu_bits_buffer(T, flat.shapes[b + "linear1.weight"][0], dev) if (save and flat.ffn_packed_bwd(b + "linear1.weight") is not None) else None
         r = ops.proj_ffn_ln_fwd(a, x, pkp, flat.f(b + "self_attn.out_proj.bias"), (g1, b1, eps), flat.f(b + "linear1.bias"),
                                 flat.f(b + "linear2.bias"), ln2, y=y, stats1=(st[2], st[3]) if save else None, z=z, h=hid,
                                 ln_b=None if last else ln1n, stats_a=(st[4], st[5]) if save else None,
                                 stats_b=(st_next[0], st_next[1]) if (save and not last) else None, want_x1=save,
-                                qkv_bias=flat.f(nb + "self_attn.in_proj_bias") if fuse_q else None, want_hn=save)
+                                qkv_bias=flat.f(nb + "self_attn.in_proj_bias") if fuse_q else None, want_hn=save, relu_bits=rbits)
         if fuse_q:  # the next block's qkv comes out of this kernel; its h is written only for the backward (dW_qkv)
             x1, x2, h_next, qkv_next = r
         else:
@@ -323,7 +325,7 @@ def _block_fwd(m: ChAdaViT, flat: FlatParams, i: int, x, rb: RaggedBatch, save: 
                                             stats1=(st[4], st[5]) if save else None, stats2=(st_next[0], st_next[1]) if save else None)
         else:
             x2 = ops.layernorm_fwd(z, ln2[0], ln2[1], ln2[2], mean=st[4] if save else None, rstd=st[5] if save else None)
-    saved = (x, h, qkv, a, lse, y, x1, hid, z, st) if save else None
+    saved = (x, h, qkv, a, lse, y, x1, hid, z, st, rbits) if save else None
     return x2, saved, h_next, st_next, qkv_next
 
 
@@ -332,7 +334,7 @@ def _block_bwd(m: ChAdaViT, flat: FlatParams, i: int, dx2, saved, rb: RaggedBatc
     side: optional HIP stream for the weight-gradient (TN) GEMMs -- they only feed the gradient slab, so they run beside
     the dX chain (LN bwd -> GEMM -> attention bwd ...) and fill its grid tails."""
     b = f"blocks.{i}."
-    x, h, qkv, a, lse, y, x1, hid, z, st = saved
+    x, h, qkv, a, lse, y, x1, hid, z, st, rbits = saved
     H = m.blocks[i].nhead
     G = flat.g
     main = torch.cuda.current_stream()
@@ -351,9 +353,15 @@ def _block_bwd(m: ChAdaViT, flat: FlatParams, i: int, dx2, saved, rb: RaggedBatc
 
     dz = ops.layernorm_bwd(dx2, z, st[4], st[5], flat.f(b + "norm2.weight"), G(b + "norm2.weight"), G(b + "norm2.bias"), ln_ws,
                            accumulate=acc)
-    dhid = ops.gemm_nt(dz, flat.wt(b + "linear2.weight"), epilogue=ops.EPI_RELUMASK, aux=hid)
-    dw(dz, hid, b + "linear2.weight", b + "linear2.bias")
-    dx1 = ops.gemm_nt(dhid, flat.wt(b + "linear1.weight"), epilogue=ops.EPI_RESID, aux=dz)
+    if rbits is not None:
+        # one launch: dH = dz W2 masked by the recorded ReLU pattern, dx1 = dz + dH W1 -- H is not re-read, dH makes no extra trip
+        dhid = torch.empty_like(hid)
+        dx1 = ops.ffn_bwd_dx(dz, flat.ffn_packed_bwd(b + "linear1.weight"), rbits, dpre=dhid)
+        dw(dz, hid, b + "linear2.weight", b + "linear2.bias")
+    else:
+        dhid = ops.gemm_nt(dz, flat.wt(b + "linear2.weight"), epilogue=ops.EPI_RELUMASK, aux=hid)
+        dw(dz, hid, b + "linear2.weight", b + "linear2.bias")
+        dx1 = ops.gemm_nt(dhid, flat.wt(b + "linear1.weight"), epilogue=ops.EPI_RESID, aux=dz)
     dw(dhid, x1, b + "linear1.weight", b + "linear1.bias")
     del dhid
     g1 = flat.f(b + "norm1.weight")

@@ -1378,10 +1378,10 @@ extern "C" int chadavit_attn_fwd(const chada_bf16* qkv_, chada_bf16* out_, float
 
 // Backward pieces.  `parts` bit 1 = delta, 2 = dQ kernel, 4 = dK/dV kernel.  With bits 1 and 2 together delta is produced by
 // the dQ kernel itself (no separate pass); dK/dV needs delta and must follow on the same stream.  parts = 7 runs everything.
-extern "C" int chadavit_attn_bwd_parts(const chada_bf16* qkv_, const chada_bf16* out_, const chada_bf16* dout_, const float* lse,
-                                       chada_bf16* dqkv_, float* delta, const int* cu_seqlens, const int* work, int n_work,
-                                       int T, int D, int H, int parts, void* stream) {
-  CHADA_ENTRY();
+// `scale` = the softmax scale 1/sqrt(head width of the MODEL); it differs from 1/sqrt(D/H) only for the zero-padded dh = 16 path.
+static int attn_bwd_launch(const chada_bf16* qkv_, const chada_bf16* out_, const chada_bf16* dout_, const float* lse,
+                           chada_bf16* dqkv_, float* delta, const int* cu_seqlens, const int* work, int n_work,
+                           int T, int D, int H, int parts, float scale, void* stream) {
   if (!qkv_ || !out_ || !dout_ || !lse || !dqkv_ || !delta || !cu_seqlens || !work || n_work <= 0 || n_work % 8 != 0 || T <= 0 || H <= 0 ||
       D % H != 0 || D % 4 != 0)
     return 1;
@@ -1391,7 +1391,6 @@ extern "C" int chadavit_attn_bwd_parts(const chada_bf16* qkv_, const chada_bf16*
   const bf16_t* dout = reinterpret_cast<const bf16_t*>(dout_);
   bf16_t* dqkv = reinterpret_cast<bf16_t*>(dqkv_);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const float scale = 1.0f / sqrtf((float)dh);
   if (dh != 32 && dh != 64 && dh != 96 && dh != 192 && dh != 384) return 2;
   static const bool use_dma = getenv("CHADAVIT_ATTN_NO_DMA") == nullptr;
   const bool fuse_delta = (parts & 3) == 3;  // delta comes out of the dQ kernel; the stand-alone pass only if dQ is not run here
@@ -1422,6 +1421,72 @@ extern "C" int chadavit_attn_bwd_parts(const chada_bf16* qkv_, const chada_bf16*
     default: return 2;
   }
 #undef BWD_CASE
+  CHADA_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int chadavit_attn_bwd_parts(const chada_bf16* qkv_, const chada_bf16* out_, const chada_bf16* dout_, const float* lse,
+                                       chada_bf16* dqkv_, float* delta, const int* cu_seqlens, const int* work, int n_work,
+                                       int T, int D, int H, int parts, void* stream) {
+  CHADA_ENTRY();
+  if (H <= 0 || D % H != 0) return 1;
+  return attn_bwd_launch(qkv_, out_, dout_, lse, dqkv_, delta, cu_seqlens, work, n_work, T, D, H, parts,
+                         1.0f / sqrtf((float)(D / H)), stream);
+}
+
+// ---- dh = 16 backward (the reference's DEFAULT constructor: 12 heads at D = 192, chada_vit.py:138-139 -- the notebook's
+// model; fine-tuning it needs a backward).  MFMA k-steps are 32 wide, so every head is widened to 32 lanes with zeros in a
+// caller-provided workspace and the dh = 32 kernels run on the widened tensors with the MODEL's softmax scale 1/sqrt(16):
+// zero lanes add nothing to QK^T, dP = dO V^T or delta, and receive exactly zero gradient, so the result is the dh = 16
+// backward bit for bit in the arithmetic that matters.  Cold path: 3 small copy kernels around the two attention kernels.
+namespace {
+// src [T, n_sec * H * 16] -> dst [T, n_sec * H * 32] (WIDEN) or back (!WIDEN); one 16-byte piece (8 bf16) per thread
+template <bool WIDEN>
+__global__ __launch_bounds__(256) void head_pad_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, long long n_pieces_wide) {
+  const uint4 zero = {0u, 0u, 0u, 0u};
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n_pieces_wide; i += (long long)gridDim.x * 256ll) {
+    const long long head = i >> 2;        // 4 pieces per widened head
+    const int piece = (int)(i & 3);
+    if (WIDEN) {
+      uint4 v = zero;
+      if (piece < 2) v = *reinterpret_cast<const uint4*>(src + head * 16 + piece * 8);
+      *reinterpret_cast<uint4*>(dst + head * 32 + piece * 8) = v;
+    } else if (piece < 2) {
+      *reinterpret_cast<uint4*>(dst + head * 16 + piece * 8) = *reinterpret_cast<const uint4*>(src + head * 32 + piece * 8);
+    }
+  }
+}
+}  // namespace
+
+extern "C" long long chadavit_attn_bwd_dh16_workspace_bytes(int T, int H) {
+  if (T <= 0 || H <= 0) return -1;
+  return (long long)T * H * 32 * 2 * 8;  // widened qkv (3), out (1), dout (1), dqkv (3)
+}
+
+extern "C" int chadavit_attn_bwd_dh16(const chada_bf16* qkv_, const chada_bf16* out_, const chada_bf16* dout_, const float* lse,
+                                      chada_bf16* dqkv_, float* delta, const int* cu_seqlens, const int* work, int n_work,
+                                      int T, int D, int H, void* workspace, long long workspace_bytes, void* stream) {
+  CHADA_ENTRY();
+  if (!qkv_ || !out_ || !dout_ || !dqkv_ || !workspace || T <= 0 || H <= 0 || D != 16 * H) return 1;
+  if (((uintptr_t)workspace & 15) != 0 || workspace_bytes < chadavit_attn_bwd_dh16_workspace_bytes(T, H)) return 1;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const long long unit = (long long)T * H * 32;  // elements of one widened [T, H*32] section
+  bf16_t* w_qkv = reinterpret_cast<bf16_t*>(workspace);
+  bf16_t* w_out = w_qkv + 3 * unit;
+  bf16_t* w_dout = w_out + unit;
+  bf16_t* w_dqkv = w_dout + unit;
+  auto grid = [](long long pieces) { long long g = (pieces + 255) / 256; return dim3((unsigned)(g > 8192 ? 8192 : g)); };
+  const long long p1 = (long long)T * H * 4, p3 = 3 * p1;
+  hipLaunchKernelGGL((head_pad_kernel<true>), grid(p3), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(qkv_), w_qkv, p3);
+  hipLaunchKernelGGL((head_pad_kernel<true>), grid(p1), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(out_), w_out, p1);
+  hipLaunchKernelGGL((head_pad_kernel<true>), grid(p1), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(dout_), w_dout, p1);
+  CHADA_CHECK_LAUNCH();
+  // NB the widened qkv is [T, 3 * (H*32)] with the q | k | v sections contiguous per row, exactly the layout the kernels index
+  const int rc = attn_bwd_launch(reinterpret_cast<const chada_bf16*>(w_qkv), reinterpret_cast<const chada_bf16*>(w_out),
+                                 reinterpret_cast<const chada_bf16*>(w_dout), lse, reinterpret_cast<chada_bf16*>(w_dqkv), delta,
+                                 cu_seqlens, work, n_work, T, 32 * H, H, 7, 0.25f, stream);
+  if (rc != 0) return rc;
+  hipLaunchKernelGGL((head_pad_kernel<false>), grid(p3), dim3(256), 0, s, w_dqkv, reinterpret_cast<bf16_t*>(dqkv_), p3);
   CHADA_CHECK_LAUNCH();
   return 0;
 }

@@ -130,12 +130,17 @@ struct FfnPro {
 // (s_waitcnt vmcnt(0)) in front of the first LDS read after an LDS-DMA load -- it cannot tell ring slots (or even different
 // __shared__ arrays) apart by itself, and would expose one full DMA latency per chunk.  Completion of the stage being read is
 // established by the caller's explicit wait + barrier.
-template <int RT, bool WRITE_H, bool DO_G1, bool DO_G2, bool GATHER, bool DO_P = false>
+// MODE 0: forward.  MODE 1: forward that also reports the ReLU pattern of chunk k in `rbits` (bit rt * 8 + j = hidden value j of
+// the lane's row in row tile rt is > 0; j = the lane's B-operand k-slot of GEMM2).  MODE 2: the BACKWARD dX pass on the same
+// machinery -- X fragments = dz, "W1" records = W2^T chunk (GEMM1 gives dH = dz W2 for the chunk, no bias), the ReLU is replaced
+// by the mask `rbits` recorded by the forward (dpre = dH where the forward's hidden value was > 0), "W2" records = W1^T chunk
+// (GEMM2 accumulates dx1 += dpre W1).
+template <int RT, bool WRITE_H, bool DO_G1, bool DO_G2, bool GATHER, bool DO_P = false, int MODE = 0>
 __device__ __forceinline__ void ffn_core(BufRsrc wrs, unsigned blk_bytes, bf16_t* __restrict__ dst,
                                          const bf16_t* __restrict__ st, const float* __restrict__ sb1,
                                          bf16_t* __restrict__ sh, bool issue, int k, int w, int l,
                                          const bf16x8 (&xf)[RT][KS1], f32x4 (&oacc)[RT][NT2], bf16x8 (&hb)[RT],
-                                         bf16x8 (&pend)[WRITE_H ? RT * 2 : 1]) {
+                                         bf16x8 (&pend)[WRITE_H ? RT * 2 : 1], unsigned& rbits) {
   constexpr int HROW = 72;
   constexpr int NPEND = WRITE_H ? RT * 2 : 1;
   const int li = l & 15, g = l >> 4;
@@ -171,10 +176,15 @@ __device__ __forceinline__ void ffn_core(BufRsrc wrs, unsigned blk_bytes, bf16_t
   }
   f32x4 hacc[RT][2];
   if constexpr (DO_G1) {
-    const f32x4 bia0 = *reinterpret_cast<const f32x4*>(sb1 + k * HC + 8 * g);
-    const f32x4 bia1 = *reinterpret_cast<const f32x4*>(sb1 + k * HC + 8 * g + 4);
+    if constexpr (MODE == 2) {
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) { hacc[rt][0] = bia0; hacc[rt][1] = bia1; }
+      for (int rt = 0; rt < RT; ++rt) { hacc[rt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; hacc[rt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    } else {
+      const f32x4 bia0 = *reinterpret_cast<const f32x4*>(sb1 + k * HC + 8 * g);
+      const f32x4 bia1 = *reinterpret_cast<const f32x4*>(sb1 + k * HC + 8 * g + 4);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) { hacc[rt][0] = bia0; hacc[rt][1] = bia1; }
+    }
   }
   // GEMM1 (KS1 steps: the two W1 fragments of a k-step) then GEMM2 (NT2 / 2 steps: two W2 fragments): every step is two
   // 1 KiB fragment reads and 2 RT MFMAs.  The reads run PD steps ahead of the MFMAs, pinned with sched_barrier -- left
@@ -211,12 +221,22 @@ __device__ __forceinline__ void ffn_core(BufRsrc wrs, unsigned blk_bytes, bf16_t
     __builtin_amdgcn_sched_barrier(0);
   }
   if constexpr (DO_G1) {
+    if constexpr (MODE == 1) rbits = 0u;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        hb[rt][r] = (bf16_t)fmaxf(hacc[rt][0][r], 0.f);
-        hb[rt][4 + r] = (bf16_t)fmaxf(hacc[rt][1][r], 0.f);
+        if constexpr (MODE == 2) {  // dpre = dH where the forward's hidden activation was positive
+          hb[rt][r] = (bf16_t)(((rbits >> (rt * 8 + r)) & 1u) ? hacc[rt][0][r] : 0.f);
+          hb[rt][4 + r] = (bf16_t)(((rbits >> (rt * 8 + 4 + r)) & 1u) ? hacc[rt][1][r] : 0.f);
+        } else {
+          hb[rt][r] = (bf16_t)fmaxf(hacc[rt][0][r], 0.f);
+          hb[rt][4 + r] = (bf16_t)fmaxf(hacc[rt][1][r], 0.f);
+          if constexpr (MODE == 1) {  // "> 0" on the bf16 value the backward would otherwise read back from H
+            rbits |= ((float)hb[rt][r] > 0.f ? 1u : 0u) << (rt * 8 + r);
+            rbits |= ((float)hb[rt][4 + r] > 0.f ? 1u : 0u) << (rt * 8 + 4 + r);
+          }
+        }
       }
       if constexpr (WRITE_H) *reinterpret_cast<bf16x8*>(sh + (w * 16 * RT + rt * 16 + li) * HROW + (k & 1) * HC + g * 8) = hb[rt];
     }
@@ -230,7 +250,11 @@ __device__ __forceinline__ void ffn_core(BufRsrc wrs, unsigned blk_bytes, bf16_t
   }
 }
 
-template <int RT, bool WRITE_H, bool PRO = false>
+// RB (MODE 1 writes, MODE 2 reads): the ReLU pattern of the hidden activation, 1 bit per (row, hidden unit), in the kernel's own
+// lane order -- record (32-row tile t = 4 * block + wave, chunk group q = k / 8) is 64 lanes x 16 bytes: dword (k % 8) / 2 of lane
+// l holds the 16 bits of chunk k (low half: even k) described at ffn_core.  M/32 tiles x FF/256 groups x 1 KiB = M * FF / 8 bytes,
+// written as whole 1 KiB records; the backward dX instance reads it with the same lane mapping, nothing else looks inside.
+template <int RT, bool WRITE_H, bool PRO = false, int MODE = 0>
 __global__ __launch_bounds__(256, (RT <= 2 ? 2 : 1)) void ffn_fwd_kernel(const bf16_t* __restrict__ X, int ldx,
                                                                          const bf16_t* __restrict__ packed,
                                                                          const float* __restrict__ b1,
@@ -238,7 +262,9 @@ __global__ __launch_bounds__(256, (RT <= 2 ? 2 : 1)) void ffn_fwd_kernel(const b
                                                                          const bf16_t* __restrict__ resid, int ldr,
                                                                          bf16_t* __restrict__ Out, int ldo,
                                                                          bf16_t* __restrict__ H, int ldh, int M, int FF, FfnLnTail ln,
-                                                                         FfnPro pro) {
+                                                                         FfnPro pro, unsigned* __restrict__ RB) {
+  static_assert(MODE == 0 || RT == 2, "the ReLU-bit record layout is defined for 32 rows per wave");
+  static_assert(!(MODE == 2 && PRO), "the backward instance has no prologue");
   constexpr int STAGE = BLK_FRAGS * FRAG_ELEMS;  // bf16 elements per stage (25 KiB)
   // forward-only instance: THREE stages, the LDS-DMA of block k+2 is issued while block k is consumed and the wait at a
   // barrier is counted (vmcnt(6): only the six DMA instructions of the newest block may still be in flight -- loads retire
@@ -262,13 +288,45 @@ __global__ __launch_bounds__(256, (RT <= 2 ? 2 : 1)) void ffn_fwd_kernel(const b
 
   bf16x8 hb[RT];
   bf16x8 pend[NPEND];
+  // ReLU-bit plumbing (see RB above): four named dwords, selected with uniform branches (a runtime-indexed vector would go to
+  // scratch)
+  unsigned rbits = 0u, mw0 = 0u, mw1 = 0u, mw2 = 0u, mw3 = 0u;
+  u32x4* const rb_rec = (MODE != 0 && RB != nullptr)
+                            ? reinterpret_cast<u32x4*>(RB) + ((size_t)(blockIdx.x * 4 + w) * (size_t)(FF / (8 * HC))) * 64 + l
+                            : nullptr;
+  u32x4 mnext = {0u, 0u, 0u, 0u};
+  if constexpr (MODE == 2) mnext = rb_rec[0];
+  auto mask_pre = [&](int k) {   // MODE 2: the bits of chunk k, in front of its GEMM1; the next record is requested 8 chunks ahead
+    if constexpr (MODE == 2) {
+      if ((k & 7) == 0) {
+        mw0 = mnext[0]; mw1 = mnext[1]; mw2 = mnext[2]; mw3 = mnext[3];
+        if (k + 8 < FF / HC) mnext = rb_rec[(size_t)((k >> 3) + 1) * 64];
+      }
+      const int q = (k >> 1) & 3;
+      const unsigned v = q == 0 ? mw0 : q == 1 ? mw1 : q == 2 ? mw2 : mw3;
+      rbits = (k & 1) ? (v >> 16) : (v & 0xFFFFu);
+    }
+  };
+  auto mask_post = [&](int k) {  // MODE 1: file the bits GEMM1 of chunk k just produced; a full record leaves every 8 chunks
+    if constexpr (MODE == 1) {
+      const int q = (k >> 1) & 3;
+      const unsigned add = (k & 1) ? (rbits << 16) : rbits;
+      if (q == 0) mw0 = (k & 1) ? (mw0 | add) : add;
+      else if (q == 1) mw1 = (k & 1) ? (mw1 | add) : add;
+      else if (q == 2) mw2 = (k & 1) ? (mw2 | add) : add;
+      else mw3 = (k & 1) ? (mw3 | add) : add;
+      if ((k & 7) == 7 && rb_rec != nullptr)
+        __builtin_nontemporal_store(u32x4{mw0, mw1, mw2, mw3}, rb_rec + (size_t)(k >> 3) * 64);
+    }
+  };
   // (no LDS read follows the first block's DMA before the barrier: issued bare)
   const BufRsrc wrs = make_rsrc(packed);
   constexpr int J3 = PRO ? 3 : 0;   // stream blocks in front of FFN block 0
   constexpr int LA = NST - 1;       // DMA look-ahead in blocks
 #pragma unroll
   for (int i = 0; i < BLK_FRAGS / 4; ++i) lds_dma16(wrs, smem + (w + 4 * i) * FRAG_ELEMS, l * 16, (w + 4 * i) * (FRAG_ELEMS * 2));
-  for (int i = tid; i < FF / 4; i += 256) reinterpret_cast<f32x4*>(sB1)[i] = reinterpret_cast<const f32x4*>(b1)[i];
+  if constexpr (MODE != 2)
+    for (int i = tid; i < FF / 4; i += 256) reinterpret_cast<f32x4*>(sB1)[i] = reinterpret_cast<const f32x4*>(b1)[i];
 
   bf16x8 xf[RT][KS1];
   int mrow[RT];
@@ -311,8 +369,8 @@ __global__ __launch_bounds__(256, (RT <= 2 ? 2 : 1)) void ffn_fwd_kernel(const b
     // FFN block 0 (and 1 with three stages)
 #pragma unroll
     for (int j = 1; j < LA; ++j)
-      ffn_core<RT, WRITE_H, false, false, false>(wrs, (unsigned)j * (STAGE * 2), smem_o + (j % NST) * STAGE, smem_o, sB1_o, sH_o, true, 0,
-                                                 w, l, xf, oacc, hb, pend);
+      ffn_core<RT, WRITE_H, false, false, false, false, MODE>(wrs, (unsigned)j * (STAGE * 2), smem_o + (j % NST) * STAGE, smem_o, sB1_o, sH_o, true, 0,
+                                                 w, l, xf, oacc, hb, pend, rbits);
     bf16x8 rv[RT][NT2 / 2];  // the residual rows: requested before the last projection step, they land under its MFMAs
     for (int j = 0; j < 3; ++j) {
       if constexpr (NST == 3) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -324,8 +382,8 @@ __global__ __launch_bounds__(256, (RT <= 2 ? 2 : 1)) void ffn_fwd_kernel(const b
           for (int p = 0; p < NT2 / 2; ++p)
             rv[rt][p] = *reinterpret_cast<const bf16x8*>(pro.Xres + (size_t)mrow[rt] * pro.ldx + 32 * p + 8 * g);
       }
-      ffn_core<RT, WRITE_H, false, false, false, true>(wrs, (unsigned)(j + LA) * (STAGE * 2), smem_o + ((j + LA) % NST) * STAGE,
-                                                       smem_o + (j % NST) * STAGE, sB1_o, sH_o, true, j, w, l, xf, oacc, hb, pend);
+      ffn_core<RT, WRITE_H, false, false, false, true, MODE>(wrs, (unsigned)(j + LA) * (STAGE * 2), smem_o + ((j + LA) % NST) * STAGE,
+                                                       smem_o + (j % NST) * STAGE, sB1_o, sH_o, true, j, w, l, xf, oacc, hb, pend, rbits);
     }
     // y = acc + bo + x ;  x1 = LN1(y) -> the X fragments (same arithmetic as the LayerNorm tail below / the stand-alone kernel)
     constexpr float invDp = 1.0f / FD;
@@ -382,43 +440,53 @@ __global__ __launch_bounds__(256, (RT <= 2 ? 2 : 1)) void ffn_fwd_kernel(const b
   if constexpr (!WRITE_H) {
     // block 1 after the X / bias loads above: they are older than it in the in-order VMEM queue (PRO: already issued)
     if constexpr (!PRO)
-      ffn_core<RT, false, false, false, false>(wrs, blk(1), smem_o + STAGE, smem_o, sB1_o, sH_o, true, 0, w, l, xf, oacc, hb, pend);
+      ffn_core<RT, false, false, false, false, false, MODE>(wrs, blk(1), smem_o + STAGE, smem_o, sB1_o, sH_o, true, 0, w, l, xf, oacc, hb, pend, rbits);
     {
       asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      ffn_core<RT, false, true, false, false>(wrs, blk(2), smem_o + 2 * STAGE, smem_o, sB1_o, sH_o, 2 <= NC, 0, w, l, xf, oacc, hb, pend);
+      mask_pre(0);
+      ffn_core<RT, false, true, false, false, false, MODE>(wrs, blk(2), smem_o + 2 * STAGE, smem_o, sB1_o, sH_o, 2 <= NC, 0, w, l, xf, oacc, hb, pend, rbits);
+      mask_post(0);
     }
     for (int k = 1; k < NC; ++k) {
       // block k has landed (LDS-DMA completion is visible only through the issuing wave's vmcnt), block k+1 may still be
       // in flight; everyone is done reading the stage block k+2 goes into (it held block k-1)
       asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      ffn_core<RT, false, true, true, false>(wrs, blk(k + 2), smem_o + ((k + 2) % 3) * STAGE, smem_o + (k % 3) * STAGE, sB1_o, sH_o,
-                                             k + 2 <= NC, k, w, l, xf, oacc, hb, pend);
+      mask_pre(k);
+      ffn_core<RT, false, true, true, false, false, MODE>(wrs, blk(k + 2), smem_o + ((k + 2) % 3) * STAGE, smem_o + (k % 3) * STAGE, sB1_o, sH_o,
+                                             k + 2 <= NC, k, w, l, xf, oacc, hb, pend, rbits);
+      mask_post(k);
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    ffn_core<RT, false, false, true, false>(wrs, 0u, smem_o, smem_o + (NC % 3) * STAGE, sB1_o, sH_o, false, NC, w, l, xf, oacc, hb, pend);
+    ffn_core<RT, false, false, true, false, false, MODE>(wrs, 0u, smem_o, smem_o + (NC % 3) * STAGE, sB1_o, sH_o, false, NC, w, l, xf, oacc, hb, pend, rbits);
   } else {
     {
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // block 0 has landed, b1 is staged
-      ffn_core<RT, true, true, false, false>(wrs, blk(1), smem_o + ((1 + J3) & 1) * STAGE, smem_o + (J3 & 1) * STAGE, sB1_o, sH_o, true,
-                                             0, w, l, xf, oacc, hb, pend);
+      mask_pre(0);
+      ffn_core<RT, true, true, false, false, false, MODE>(wrs, blk(1), smem_o + ((1 + J3) & 1) * STAGE, smem_o + (J3 & 1) * STAGE, sB1_o, sH_o, true,
+                                             0, w, l, xf, oacc, hb, pend, rbits);
+      mask_post(0);
     }
     // NC is even: iterations come in (odd, even) pairs
     for (int k = 1; k < NC; k += 2) {
       {  // odd k
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        ffn_core<RT, true, true, true, true>(wrs, blk(k + 1), smem_o + ((k + 1 + J3) & 1) * STAGE, smem_o + ((k + J3) & 1) * STAGE, sB1_o,
-                                             sH_o, true, k, w, l, xf, oacc, hb, pend);
+        mask_pre(k);
+        ffn_core<RT, true, true, true, true, false, MODE>(wrs, blk(k + 1), smem_o + ((k + 1 + J3) & 1) * STAGE, smem_o + ((k + J3) & 1) * STAGE, sB1_o,
+                                             sH_o, true, k, w, l, xf, oacc, hb, pend, rbits);
+        mask_post(k);
       }
       if (k + 1 < NC) {  // even k + 1
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         store_h(k - 1);
-        ffn_core<RT, true, true, true, false>(wrs, blk(k + 2), smem_o + ((k + J3) & 1) * STAGE, smem_o + ((k + 1 + J3) & 1) * STAGE, sB1_o,
-                                              sH_o, true, k + 1, w, l, xf, oacc, hb, pend);
+        mask_pre(k + 1);
+        ffn_core<RT, true, true, true, false, false, MODE>(wrs, blk(k + 2), smem_o + ((k + J3) & 1) * STAGE, smem_o + ((k + 1 + J3) & 1) * STAGE, sB1_o,
+                                              sH_o, true, k + 1, w, l, xf, oacc, hb, pend, rbits);
+        mask_post(k + 1);
       }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     store_h(NC - 2);
-    ffn_core<RT, true, false, true, false>(wrs, 0u, smem_o, smem_o + ((NC + J3) & 1) * STAGE, sB1_o, sH_o, false, NC, w, l, xf, oacc, hb, pend);
+    ffn_core<RT, true, false, true, false, false, MODE>(wrs, 0u, smem_o, smem_o + ((NC + J3) & 1) * STAGE, sB1_o, sH_o, false, NC, w, l, xf, oacc, hb, pend, rbits);
   }
 
   // ---- epilogue: + b2 + residual (+ LayerNorm tail), 16-byte stores straight from the accumulators
@@ -443,8 +511,11 @@ __global__ __launch_bounds__(256, (RT <= 2 ? 2 : 1)) void ffn_fwd_kernel(const b
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       const int col = 32 * p + 8 * g;
-      f32x4 v0 = oacc[rt][2 * p] + *reinterpret_cast<const f32x4*>(b2 + col);
-      f32x4 v1 = oacc[rt][2 * p + 1] + *reinterpret_cast<const f32x4*>(b2 + col + 4);
+      f32x4 v0 = oacc[rt][2 * p], v1 = oacc[rt][2 * p + 1];
+      if constexpr (MODE != 2) {
+        v0 += *reinterpret_cast<const f32x4*>(b2 + col);
+        v1 += *reinterpret_cast<const f32x4*>(b2 + col + 4);
+      }
       if constexpr (PRO) {  // the residual is x1 = the X fragment of this pair: same rows, same 8 columns, already in registers
 #pragma unroll
         for (int r = 0; r < 4; ++r) { v0[r] += (float)xf[rt][p][r]; v1[r] += (float)xf[rt][p][4 + r]; }
@@ -530,8 +601,8 @@ __global__ __launch_bounds__(256, (RT <= 2 ? 2 : 1)) void ffn_fwd_kernel(const b
       auto qblk = [&](int q) { return (unsigned)(pro.qkv_at + q) * (STAGE * 2); };
 #pragma unroll
       for (int q = 0; q < LA; ++q)
-        ffn_core<RT, WRITE_H, false, false, false>(wrs, qblk(q), smem_o + (q % NST) * STAGE, smem_o, sB1_o, sH_o, true, 0, w, l, xf, oacc, hb,
-                                                   pend);
+        ffn_core<RT, WRITE_H, false, false, false, false, MODE>(wrs, qblk(q), smem_o + (q % NST) * STAGE, smem_o, sB1_o, sH_o, true, 0, w, l, xf, oacc, hb,
+                                                   pend, rbits);
       for (int c = 0; c < 3; ++c) {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
@@ -541,8 +612,8 @@ __global__ __launch_bounds__(256, (RT <= 2 ? 2 : 1)) void ffn_fwd_kernel(const b
           const int q = 3 * c + j;
           if constexpr (NST == 3) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
           else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-          ffn_core<RT, WRITE_H, false, false, false, true>(wrs, qblk(q + LA), smem_o + ((q + LA) % NST) * STAGE, smem_o + (q % NST) * STAGE,
-                                                           sB1_o, sH_o, q + LA < 9, j, w, l, xf, oacc, hb, pend);
+          ffn_core<RT, WRITE_H, false, false, false, true, MODE>(wrs, qblk(q + LA), smem_o + ((q + LA) % NST) * STAGE, smem_o + (q % NST) * STAGE,
+                                                           sB1_o, sH_o, q + LA < 9, j, w, l, xf, oacc, hb, pend, rbits);
         }
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
@@ -657,29 +728,34 @@ extern "C" int chadavit_ffn_pack_batched(const chada_bf16* slab, void* packed, c
 namespace {
 int launch_ffn(const chada_bf16* X, int ldx, const void* packed, const float* b1, const float* b2, const chada_bf16* resid, int ldr,
                chada_bf16* Out, int ldo, chada_bf16* H, int ldh, int M, int D, int FF, int rows_per_wave, const FfnLnTail& ln,
-               void* stream, const FfnPro* pro = nullptr) {
-  if ((!X && !pro) || !packed || !b1 || !b2 || M <= 0 || (!Out && !ln.mode)) return 1;
+               void* stream, const FfnPro* pro = nullptr, void* relu_bits = nullptr, bool bwd = false) {
+  if ((!X && !pro) || !packed || (!bwd && (!b1 || !b2)) || M <= 0 || (!Out && !ln.mode)) return 1;
+  if (bwd && (!relu_bits || pro || ln.mode)) return 1;
   if (D != FD || FF < 2 * HC || FF > MAX_FF || FF % (2 * HC) != 0 || ldx % 8 != 0 || (Out && ldo % 8 != 0) || (resid && ldr % 8 != 0) ||
       (H && ldh % 8 != 0))
     return 2;
+  if (relu_bits && (FF % (8 * HC) != 0 || rows_per_wave != 32 || ((uintptr_t)relu_bits & 15) != 0)) return 2;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const bf16_t* x = reinterpret_cast<const bf16_t*>(X);
   const bf16_t* pk = reinterpret_cast<const bf16_t*>(packed);
   const bf16_t* rs = reinterpret_cast<const bf16_t*>(resid);
   bf16_t* o = reinterpret_cast<bf16_t*>(Out);
   bf16_t* h = reinterpret_cast<bf16_t*>(H);
-#define FFN_LAUNCH(RT, WH)                                                                                              \
-  hipLaunchKernelGGL((ffn_fwd_kernel<RT, WH>), dim3((M + 64 * RT - 1) / (64 * RT)), dim3(256), 0, s, x, ldx, pk, b1, b2, rs, \
-                     ldr, o, ldo, h, ldh, M, FF, ln, FfnPro{})
-  if (pro) {  // with the out-proj + norm1 prologue (32 rows per wave only)
-    if (h) hipLaunchKernelGGL((ffn_fwd_kernel<2, true, true>), dim3((M + 127) / 128), dim3(256), 0, s, x, ldx, pk, b1, b2, rs, ldr, o, ldo,
-                              h, ldh, M, FF, ln, *pro);
-    else hipLaunchKernelGGL((ffn_fwd_kernel<2, false, true>), dim3((M + 127) / 128), dim3(256), 0, s, x, ldx, pk, b1, b2, rs, ldr, o, ldo,
-                            h, ldh, M, FF, ln, *pro);
+  unsigned* rb = reinterpret_cast<unsigned*>(relu_bits);
+#define FFN_LAUNCH(RT, WH, PR, MD)                                                                                      \
+  hipLaunchKernelGGL((ffn_fwd_kernel<RT, WH, PR, MD>), dim3((M + 64 * RT - 1) / (64 * RT)), dim3(256), 0, s, x, ldx, pk, b1, b2, rs, \
+                     ldr, o, ldo, h, ldh, M, FF, ln, (PR ? *pro : FfnPro{}), rb)
+  if (bwd) {  // dX pass: X = dz, packed = [W2^T | W1^T] stream, H (optional) receives dpre
+    if (h) FFN_LAUNCH(2, true, false, 2); else FFN_LAUNCH(2, false, false, 2);
+  } else if (pro) {  // with the out-proj + norm1 prologue (32 rows per wave only)
+    if (rb) { if (h) FFN_LAUNCH(2, true, true, 1); else FFN_LAUNCH(2, false, true, 1); }
+    else { if (h) FFN_LAUNCH(2, true, true, 0); else FFN_LAUNCH(2, false, true, 0); }
   } else if (rows_per_wave == 64) {
-    if (h) FFN_LAUNCH(4, true); else FFN_LAUNCH(4, false);
+    if (h) FFN_LAUNCH(4, true, false, 0); else FFN_LAUNCH(4, false, false, 0);
+  } else if (rb) {
+    if (h) FFN_LAUNCH(2, true, false, 1); else FFN_LAUNCH(2, false, false, 1);
   } else {
-    if (h) FFN_LAUNCH(2, true); else FFN_LAUNCH(2, false);
+    if (h) FFN_LAUNCH(2, true, false, 0); else FFN_LAUNCH(2, false, false, 0);
   }
 #undef FFN_LAUNCH
   CHADA_CHECK_LAUNCH();
@@ -688,11 +764,28 @@ int launch_ffn(const chada_bf16* X, int ldx, const void* packed, const float* b1
 }  // namespace
 
 extern "C" int chadavit_ffn_fwd(const chada_bf16* X, int ldx, const void* packed, const float* b1, const float* b2,
-                                const chada_bf16* resid, int ldr, chada_bf16* Out, int ldo, chada_bf16* H, int ldh, int M, int D, int FF,
-                                int rows_per_wave, void* stream) {
+                                const chada_bf16* resid, int ldr, chada_bf16* Out, int ldo, chada_bf16* H, int ldh, void* relu_bits,
+                                int M, int D, int FF, int rows_per_wave, void* stream) {
   CHADA_ENTRY();
   FfnLnTail ln{};
-  return launch_ffn(X, ldx, packed, b1, b2, resid, ldr, Out, ldo, H, ldh, M, D, FF, rows_per_wave, ln, stream);
+  return launch_ffn(X, ldx, packed, b1, b2, resid, ldr, Out, ldo, H, ldh, M, D, FF, rows_per_wave, ln, stream, nullptr, relu_bits);
+}
+
+extern "C" long long chadavit_relu_bits_bytes(int M, int FF) {
+  if (M <= 0 || FF <= 0 || FF % (8 * HC) != 0) return -1;
+  return (long long)((M + 127) / 128) * 4 * (FF / (8 * HC)) * 1024;
+}
+
+// dX pass of the FFN backward in one launch, nothing 2048-wide in HBM:  dX1 = dZ + ((dZ W2) * [H > 0]) W1.
+// `packed_bwd` = chadavit_ffn_pack[_batched] applied to (W2^T as "W1", W1^T as "W2"), i.e. to the [FF x D] and [D x FF] transposed
+// bf16 copies; `relu_bits` = what the forward recorded.  dPre (optional, [M x FF]) receives (dZ W2) * [H > 0] for a separate dW1 pass.
+extern "C" int chadavit_ffn_bwd_dx(const chada_bf16* dZ, int lddz, const void* packed_bwd, const void* relu_bits, chada_bf16* dX1,
+                                   int lddx, chada_bf16* dPre, int lddp, int M, int D, int FF, void* stream) {
+  CHADA_ENTRY();
+  if (!dZ || !dX1 || !relu_bits) return 1;
+  FfnLnTail ln{};
+  return launch_ffn(dZ, lddz, packed_bwd, nullptr, nullptr, dZ, lddz, dX1, lddx, dPre, lddp, M, D, FF, 32, ln, stream, nullptr,
+                    const_cast<void*>(relu_bits), true);
 }
 
 extern "C" int chadavit_ffn_ln_fwd(const chada_bf16* X, int ldx, const void* packed, const float* b1, const float* b2,
@@ -719,7 +812,7 @@ extern "C" int chadavit_block_fwd(const chada_bf16* A, int lda, const chada_bf16
                                   float* mean1, float* rstd1, const float* b1, const float* b2, chada_bf16* Z, int ldz, chada_bf16* H,
                                   int ldh, const float* gamma_a, const float* beta_a, float eps_a, chada_bf16* X2, float* mean_a,
                                   float* rstd_a, const float* gamma_b, const float* beta_b, float eps_b, chada_bf16* Hn, float* mean_b,
-                                  float* rstd_b, chada_bf16* QKV, int ldqkv, const float* bqkv, int M, int D, int FF, void* stream);
+                                  float* rstd_b, chada_bf16* QKV, int ldqkv, const float* bqkv, void* relu_bits, int M, int D, int FF, void* stream);
 
 extern "C" int chadavit_proj_ffn_ln_fwd(const chada_bf16* A, int lda, const chada_bf16* Xres, int ldxr, const void* packed, const float* bo,
                                         const float* gamma1, const float* beta1, float eps1, chada_bf16* Y, int ldy, chada_bf16* X1,
@@ -728,8 +821,8 @@ extern "C" int chadavit_proj_ffn_ln_fwd(const chada_bf16* A, int lda, const chad
                                         float* mean_a, float* rstd_a, const float* gamma_b, const float* beta_b, float eps_b,
                                         chada_bf16* Hn, float* mean_b, float* rstd_b, int M, int D, int FF, void* stream) {
   return chadavit_block_fwd(A, lda, Xres, ldxr, packed, bo, gamma1, beta1, eps1, Y, ldy, X1, ldx1, mean1, rstd1, b1, b2, Z, ldz, H, ldh,
-                            gamma_a, beta_a, eps_a, X2, mean_a, rstd_a, gamma_b, beta_b, eps_b, Hn, mean_b, rstd_b, nullptr, 0, nullptr, M, D,
-                            FF, stream);
+                            gamma_a, beta_a, eps_a, X2, mean_a, rstd_a, gamma_b, beta_b, eps_b, Hn, mean_b, rstd_b, nullptr, 0, nullptr, nullptr,
+                            M, D, FF, stream);
 }
 
 // ... plus, optionally, the NEXT block's QKV projection (QKV != NULL: needs gamma_b / beta_b; Hn itself becomes optional)
@@ -738,7 +831,7 @@ extern "C" int chadavit_block_fwd(const chada_bf16* A, int lda, const chada_bf16
                                   float* mean1, float* rstd1, const float* b1, const float* b2, chada_bf16* Z, int ldz, chada_bf16* H,
                                   int ldh, const float* gamma_a, const float* beta_a, float eps_a, chada_bf16* X2, float* mean_a,
                                   float* rstd_a, const float* gamma_b, const float* beta_b, float eps_b, chada_bf16* Hn, float* mean_b,
-                                  float* rstd_b, chada_bf16* QKV, int ldqkv, const float* bqkv, int M, int D, int FF, void* stream) {
+                                  float* rstd_b, chada_bf16* QKV, int ldqkv, const float* bqkv, void* relu_bits, int M, int D, int FF, void* stream) {
   CHADA_ENTRY();
   if (QKV && (!gamma_b || !beta_b || !bqkv || ldqkv % 8 != 0)) return 1;
   if (!A || !Xres || !bo || !gamma1 || !beta1 || (mean1 == nullptr) != (rstd1 == nullptr)) return 1;
@@ -760,5 +853,5 @@ extern "C" int chadavit_block_fwd(const chada_bf16* A, int lda, const chada_bf16
   pro.mean1 = mean1; pro.rstd1 = rstd1;
   pro.QKV = reinterpret_cast<bf16_t*>(QKV); pro.ldqkv = ldqkv; pro.bqkv = bqkv; pro.qkv_at = FF / HC + 1 + 3;
   // the FFN's input rows and its residual are x1: both come from the X fragments the prologue leaves in registers
-  return launch_ffn(nullptr, 0, packed, b1, b2, nullptr, 0, Z, ldz, H, ldh, M, D, FF, 32, ln, stream, &pro);
+  return launch_ffn(nullptr, 0, packed, b1, b2, nullptr, 0, Z, ldz, H, ldh, M, D, FF, 32, ln, stream, &pro, relu_bits);
 }

@@ -101,6 +101,21 @@ class FlatParams:
             else:
                 n = ops.ffn_packed_bytes(*self._pk_shape) // 2
                 self._pk[w1] = self._pk_buf[pk_desc[3 * i + 2]:pk_desc[3 * i + 2] + n]
+        # the same fragment-major stream for the BACKWARD dX pass (ops.ffn_bwd_dx): W2^T in the W1 slot, W1^T in the W2 slot, both
+        # taken from the transposed bf16 copies above; rebuilt with them
+        self._pkb: Dict[str, torch.Tensor] = {}
+        pkb_off, pkb_desc, t_off_of = 0, [], {n: desc[4 * i + 1] for i, n in enumerate(self.transpose_names)}
+        if self._pk_shape is not None:
+            nb = ops.ffn_packed_bytes(*self._pk_shape) // 2
+            for w1, (_, w2) in self._pk_src.items():
+                if w1 in t_off_of and w2 in t_off_of:
+                    pkb_desc += [t_off_of[w2], t_off_of[w1], pkb_off]
+                    pkb_off += nb
+        self._pkb_buf = torch.empty(max(pkb_off, 1), device=self.device, dtype=torch.bfloat16)
+        self._pkb_desc = torch.tensor(pkb_desc, device=self.device, dtype=torch.int64) if pkb_desc else None
+        if pkb_desc:
+            for i, w1 in enumerate(self._pk_src):
+                self._pkb[w1] = self._pkb_buf[pkb_desc[3 * i + 2]:pkb_desc[3 * i + 2] + nb]
         self._cast_version = None
         self._cast_version_t = None
         self._manual_version = 0
@@ -125,6 +140,10 @@ class FlatParams:
     def ffn_packed(self, w1_name: str) -> Optional[torch.Tensor]:
         """Packed (W1, W2) stream keyed by the first linear's weight name, or None if the shape has no fused kernel."""
         return self._pk.get(w1_name)
+
+    def ffn_packed_bwd(self, w1_name: str) -> Optional[torch.Tensor]:
+        """[W2^T | W1^T] stream of the block's FFN for ops.ffn_bwd_dx, or None."""
+        return self._pkb.get(w1_name)
 
     def proj_ffn_packed(self, w1_name: str) -> Optional[torch.Tensor]:
         """[Wo | FFN | next QKV] stream of the block (ops.proj_ffn_ln_fwd), or None."""
@@ -171,6 +190,8 @@ class FlatParams:
         if need_transposes and ver != self._cast_version_t:
             if self._t_desc is not None:
                 ops.cast_transpose_batched(self.flat, self._t_buf, self._t_desc, len(self.transpose_names), self._t_max_tiles)
+                if self._pkb_desc is not None:
+                    ops.ffn_pack_batched(self._t_buf, self._pkb_buf, self._pkb_desc, len(self._pkb), *self._pk_shape)
             self._cast_version_t = ver
 
     # ---- gradient views handed to autograd users ---------------------------------------------------

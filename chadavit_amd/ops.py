@@ -165,8 +165,37 @@ def ffn_pack(w1, w2, packed=None):
 
 
 @_timed(lambda x, packed, b1, b2, *a, **k: ("ffn_fwd", x.shape[0], x.shape[1], (packed.numel() // 12288 - 1) * 32, k.get("h") is not None))
-def ffn_fwd(x, packed, b1, b2, resid=None, out=None, h=None, rows_per_wave=32):
-    """out = resid + b2 + relu(x W1^T + b1) W2^T in one kernel; `h` (M, FF) receives relu(.) when given."""
+def relu_bits_buffer(M, FF, device):
+    """Caller-owned buffer for the ReLU pattern the fused forward records for the backward (M * FF / 8 bytes)."""
+    n = int(lib().chadavit_relu_bits_bytes(c_int(M), c_int(FF)))
+    if n < 0:
+        raise RuntimeError(f"relu_bits: unsupported shape M={M} FF={FF}")
+    return torch.empty(n, device=device, dtype=torch.uint8)
+
+
+@_timed(lambda dz, packed_bwd, relu_bits, *a, **k: ("ffn_bwd_dx", dz.shape[0], dz.shape[1], (packed_bwd.numel() // 12288 - 1) * 32, k.get("dpre") is not None))
+def ffn_bwd_dx(dz, packed_bwd, relu_bits, dx1=None, dpre=None):
+    """dx1 = dz + ((dz W2) * [H > 0]) W1 in one kernel (H > 0 from the forward's relu_bits); `dpre` (M, FF) optionally receives
+    (dz W2) * [H > 0].  packed_bwd: FlatParams.ffn_packed_bwd."""
+    _req(dz, BF16, "dz"); _req(packed_bwd, BF16, "packed_bwd"); _req(relu_bits, torch.uint8, "relu_bits")
+    M, D = dz.shape
+    FF = (packed_bwd.numel() // 12288 - 1) * 32
+    if dx1 is None:
+        dx1 = torch.empty((M, D), device=dz.device, dtype=BF16)
+    _req(dx1, BF16, "dx1")
+    if dpre is not None:
+        _req(dpre, BF16, "dpre")
+    if relu_bits.numel() < int(lib().chadavit_relu_bits_bytes(c_int(M), c_int(FF))):
+        raise RuntimeError("ffn_bwd_dx: relu_bits buffer too small")
+    rc = lib().chadavit_ffn_bwd_dx(_ptr(dz), c_int(dz.stride(0)), _ptr(packed_bwd), _ptr(relu_bits), _ptr(dx1), c_int(dx1.stride(0)),
+                                   _ptr(dpre), c_int(dpre.stride(0) if dpre is not None else 0), c_int(M), c_int(D), c_int(FF), _stream())
+    _chk(rc, "chadavit_ffn_bwd_dx")
+    return dx1
+
+
+def ffn_fwd(x, packed, b1, b2, resid=None, out=None, h=None, rows_per_wave=32, relu_bits=None):
+    """out = resid + b2 + relu(x W1^T + b1) W2^T in one kernel; `h` (M, FF) receives relu(.) when given, `relu_bits` its sign
+    pattern (relu_bits_buffer)."""
     _req(x, BF16, "x"); _req(packed, BF16, "packed"); _req(b1, F32, "b1"); _req(b2, F32, "b2")
     M, D = x.shape
     FF = (packed.numel() // 12288 - 1) * 32
@@ -178,8 +207,8 @@ def ffn_fwd(x, packed, b1, b2, resid=None, out=None, h=None, rows_per_wave=32):
     if h is not None:
         _req(h, BF16, "h")
     rc = lib().chadavit_ffn_fwd(_ptr(x), c_int(x.stride(0)), _ptr(packed), _ptr(b1), _ptr(b2), _ptr(resid), c_int(resid.stride(0) if resid is not None else 0),
-                                _ptr(out), c_int(out.stride(0)), _ptr(h), c_int(h.stride(0) if h is not None else 0), c_int(M), c_int(D),
-                                c_int(FF), c_int(rows_per_wave), _stream())
+                                _ptr(out), c_int(out.stride(0)), _ptr(h), c_int(h.stride(0) if h is not None else 0), _ptr(relu_bits),
+                                c_int(M), c_int(D), c_int(FF), c_int(rows_per_wave), _stream())
     _chk(rc, "chadavit_ffn_fwd")
     return out
 
@@ -232,9 +261,9 @@ def ffn_pack_proj_batched(slab, packed, desc, n_layers, D, FF):
          "chadavit_ffn_pack_proj_batched")
 
 
-@_timed(lambda a, xres, packed, *r, **k: ("proj_ffn_ln_fwd", a.shape[0], a.shape[1], (packed.numel() // 12288 - 13) * 32, k.get("h") is not None, k.get("ln_b") is not None, k.get("qkv_bias") is not None))
+@_timed(lambda a, xres, packed, *r, **k: ("proj_ffn_ln_fwd", a.shape[0], a.shape[1], (packed.numel() // 12288 - 13) * 32, k.get("h") is not None, k.get("ln_b") is not None, k.get("qkv_bias") is not None, k.get("relu_bits") is not None))
 def proj_ffn_ln_fwd(a, xres, packed, bo, ln1, b1, b2, ln_a, y=None, x1=None, stats1=None, z=None, h=None, ln_b=None, stats_a=None,
-                    stats_b=None, want_x1=True, qkv_bias=None, qkv=None, want_hn=True):
+                    stats_b=None, want_x1=True, qkv_bias=None, qkv=None, want_hn=True, relu_bits=None):
     """One block from the attention output on: y = xres + a Wo^T + bo; x1 = LN1(y); z = x1 + b2 + relu(x1 W1^T + b1) W2^T;
     x2 = LN_a(z); hn = LN_b(x2).  `packed` = [Wo | FFN] stream (FlatParams.proj_ffn_packed).  x1 is written only when wanted
     (the backward needs it; the kernel itself keeps it in registers).  With qkv_bias (and the next block's in_proj weight in
@@ -272,8 +301,8 @@ def proj_ffn_ln_fwd(a, xres, packed, bo, ln1, b1, b2, ln_a, y=None, x1=None, sta
                                         c_int(z.stride(0) if z is not None else 0), _ptr(h), c_int(h.stride(0) if h is not None else 0),
                                         _ptr(ga), _ptr(ba), c_float(ea), _ptr(x2), _ptr(sa[0]), _ptr(sa[1]), _ptr(gb), _ptr(bb),
                                         c_float(eb), _ptr(hn), _ptr(sb[0]), _ptr(sb[1]), _ptr(qkv if qkv_bias is not None else None),
-                                        c_int(qkv.stride(0) if qkv_bias is not None else 0), _ptr(qkv_bias), c_int(M), c_int(D), c_int(FF),
-                                        _stream())
+                                        c_int(qkv.stride(0) if qkv_bias is not None else 0), _ptr(qkv_bias), _ptr(relu_bits), c_int(M),
+                                        c_int(D), c_int(FF), _stream())
     _chk(rc, "chadavit_block_fwd")
     if qkv_bias is not None:
         return x1, x2, hn, qkv
@@ -379,6 +408,13 @@ def attn_bwd(qkv, out, dout, lse, cu, work, H, dqkv=None, delta=None, side=None)
         dqkv = torch.empty_like(qkv)
     if delta is None:
         delta = torch.empty((H, T), device=qkv.device, dtype=F32)
+
+    if D // H == 16:  # 12-head default constructor: widened-head path, caller-owned workspace
+        ws = torch.empty(int(lib().chadavit_attn_bwd_dh16_workspace_bytes(c_int(T), c_int(H))), device=qkv.device, dtype=torch.uint8)
+        rc = lib().chadavit_attn_bwd_dh16(_ptr(qkv), _ptr(out), _ptr(dout), _ptr(lse), _ptr(dqkv), _ptr(delta), _ptr(cu), _ptr(work),
+                                          c_int(work.shape[0]), c_int(T), c_int(D), c_int(H), _ptr(ws), c_ll(ws.numel()), _stream())
+        _chk(rc, "chadavit_attn_bwd_dh16")
+        return dqkv
 
     def call(parts, stream):
         rc = lib().chadavit_attn_bwd_parts(_ptr(qkv), _ptr(out), _ptr(dout), _ptr(lse), _ptr(dqkv), _ptr(delta), _ptr(cu), _ptr(work),

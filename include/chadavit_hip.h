@@ -112,6 +112,14 @@ int chadavit_attn_bwd(const chada_bf16* qkv, const chada_bf16* out, const chada_
 int chadavit_attn_bwd_parts(const chada_bf16* qkv, const chada_bf16* out, const chada_bf16* dout, const float* lse,
                             chada_bf16* dqkv, float* delta, const int* cu_seqlens, const int* work, int n_work, int T,
                             int D, int H, int parts, void* stream);
+/* bwd for dh = D/H = 16 -- the reference's DEFAULT constructor (12 heads at D = 192, src/backbones/vit/chada_vit.py:138-139; the
+ * notebook's model): heads are widened to 32 lanes with zeros in `workspace` (>= chadavit_attn_bwd_dh16_workspace_bytes, 16-byte
+ * aligned, caller-owned) and the dh = 32 kernels run with the model's softmax scale 1/sqrt(16).  Replaces autograd of
+ * nn.MultiheadAttention at chada_vit.py:105-111 for that construction. */
+long long chadavit_attn_bwd_dh16_workspace_bytes(int T, int H);
+int chadavit_attn_bwd_dh16(const chada_bf16* qkv, const chada_bf16* out, const chada_bf16* dout, const float* lse,
+                           chada_bf16* dqkv, float* delta, const int* cu_seqlens, const int* work, int n_work, int T,
+                           int D, int H, void* workspace, long long workspace_bytes, void* stream);
 int chadavit_attn_tile_rows(void); /* rows per work tile (q tile == kv tile) */
 
 /* ---------------------------------------------------------------------------------------------
@@ -184,7 +192,18 @@ long long chadavit_ffn_packed_bytes(int D, int FF);
 int chadavit_ffn_pack(const chada_bf16* W1, const chada_bf16* W2, void* packed, int D, int FF, void* stream);
 int chadavit_ffn_fwd(const chada_bf16* X, int ldx, const void* packed, const float* b1, const float* b2,
                      const chada_bf16* resid, int ldr,
-                     chada_bf16* Out, int ldo, chada_bf16* H, int ldh, int M, int D, int FF, int rows_per_wave, void* stream);
+                     chada_bf16* Out, int ldo, chada_bf16* H, int ldh, void* relu_bits, int M, int D, int FF, int rows_per_wave,
+                     void* stream);
+/* ReLU pattern of the FFN's hidden activation, recorded by the forward INSTEAD of the [M x FF] hidden tensor (1 bit per element:
+ * M * FF / 8 bytes, opaque lane-order records of 1 KiB; relu_bits buffers are 16-byte aligned, caller-owned, >= this many bytes;
+ * FF % 256 == 0).  Consumed by chadavit_ffn_bwd_dx below. */
+long long chadavit_relu_bits_bytes(int M, int FF);
+/* dX pass of the FFN backward (autograd of linear2(relu(linear1(x))) + x w.r.t. x, chada_vit.py:113-115) in ONE launch with nothing
+ * FF-wide in HBM:  dX1 = dZ + ((dZ W2) * [H > 0]) W1.  packed_bwd = chadavit_ffn_pack / _pack_batched applied to the TRANSPOSED bf16
+ * copies (W2^T [FF x D] in the W1 slot, W1^T [D x FF] in the W2 slot).  dPre (optional, [M x FF] bf16) also receives
+ * (dZ W2) * [H > 0] for a stand-alone dW1 GEMM. */
+int chadavit_ffn_bwd_dx(const chada_bf16* dZ, int lddz, const void* packed_bwd, const void* relu_bits, chada_bf16* dX1, int lddx,
+                        chada_bf16* dPre, int lddp, int M, int D, int FF, void* stream);
 /* Weighted k-NN vote of the evaluation path (WeightedKNNClassifier.compute, src/utils/knn.py:141-161): sims [n_test, ld_sims]
  * fp32 similarities to the n_train bank samples (cosine dot products, or 1/(dist+eps)); the k most similar vote for
  * train_targets[j] with weight exp(sim/temperature) (use_exp) or sim; top_classes [n_test, top] = classes by vote mass, best
@@ -233,7 +252,7 @@ int chadavit_block_fwd(const chada_bf16* A, int lda, const chada_bf16* Xres, int
                        float* mean1, float* rstd1, const float* b1, const float* b2, chada_bf16* Z, int ldz, chada_bf16* H, int ldh,
                        const float* gamma_a, const float* beta_a, float eps_a, chada_bf16* X2, float* mean_a, float* rstd_a,
                        const float* gamma_b, const float* beta_b, float eps_b, chada_bf16* Hn, float* mean_b, float* rstd_b,
-                       chada_bf16* QKV, int ldqkv, const float* bqkv, int M, int D, int FF, void* stream);
+                       chada_bf16* QKV, int ldqkv, const float* bqkv, void* relu_bits, int M, int D, int FF, void* stream);
 int chadavit_proj_ffn_ln_fwd(const chada_bf16* A, int lda, const chada_bf16* Xres, int ldxr, const void* packed, const float* bo,
                              const float* gamma1, const float* beta1, float eps1, chada_bf16* Y, int ldy, chada_bf16* X1, int ldx1,
                              float* mean1, float* rstd1, const float* b1, const float* b2, chada_bf16* Z, int ldz, chada_bf16* H,

@@ -108,7 +108,8 @@ def test_bench_contract_with_two_ranks():
     s.close()
     env = dict(os.environ, CHADAVIT_DIST_BACKEND="gloo", CHADAVIT_SINGLE_DEVICE="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "16", "--steps", "2", "--warmup", "1"]
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "16", "--steps", "2", "--warmup", "1",
+           "--verify-equal-batch"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -116,3 +117,8 @@ def test_bench_contract_with_two_ranks():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 32 and out["scaling"] == "weak" and out["value"] > 0
     assert out["roofline"] is not None and out["roofline"]["avg_us_in_step"] > 0 and "cpu_baseline" not in out
+    # the collectives of a step are reported (14 gradient spans: 12 blocks + final norm + tokenizer, + the head) ...
+    assert out["rccl"]["world"] == 2 and out["rccl"]["spans"] >= 14 and out["rccl"]["bytes_per_step"] > 4 * 17e6
+    # ... and the N-rank step equals the single-rank step on the same global batch (self-check of the first multi-GPU run)
+    v = out["verify_equal_batch"]
+    assert v["ok"] and v["rel_loss"] <= 3e-2 and v["rel_gradnorm"] <= 3e-2, v

@@ -162,6 +162,48 @@ def test_proj_ffn_ln_block_kernel_matches_the_separate_kernels(M, save, two):
             assert torch.equal(qkv, ops.gemm_nt(hn, wq, bias=bq)), float((qkv.float() - ops.gemm_nt(hn, wq, bias=bq).float()).abs().max())
 
 
+@pytest.mark.parametrize("M", [1000, 70001, 333, 128])
+def test_ffn_bwd_dx_from_relu_bits(M):
+    """Backward dX pass of the FFN without a hidden-wide tensor: the forward records 1 bit per hidden activation (relu_bits), the
+    backward kernel computes dx1 = dz + ((dz W2) * [H > 0]) W1 in one launch.  Checked against fp32 torch on the same bf16 inputs
+    (the mask taken from the H the forward also wrote here), and bit for bit on dpre against the mask itself; recording the bits
+    must not change any forward output."""
+    from chadavit_amd import ops
+    dev = _dev()
+    D, FF = 192, 2048
+    x = _rand((M, D), 81, 1.0).bfloat16().to(dev)
+    dz = _rand((M, D), 82, 1.0).bfloat16().to(dev)
+    w1 = (_rand((FF, D), 83, 1.0) / math.sqrt(D)).bfloat16().to(dev)
+    w2 = (_rand((D, FF), 84, 1.0) / math.sqrt(FF)).bfloat16().to(dev)
+    b1, b2 = _rand((FF,), 85, 0.3).to(dev), _rand((D,), 86, 0.1).to(dev)
+    pk = ops.ffn_pack(w1, w2)
+    h0 = torch.empty((M, FF), device=dev, dtype=torch.bfloat16)
+    out0 = ops.ffn_fwd(x, pk, b1, b2, resid=x, h=h0)
+    bits = ops.relu_bits_buffer(M, FF, dev)
+    bits.fill_(0xA5)
+    for with_h in (True, False):   # the two instances that record bits: beside H (2 LDS stages) and instead of it (3 stages)
+        h = torch.empty_like(h0) if with_h else None
+        out = ops.ffn_fwd(x, pk, b1, b2, resid=x, h=h, relu_bits=bits)
+        assert torch.equal(out, out0) and (h is None or torch.equal(h, h0))
+        pkb = ops.ffn_pack(w2.t().contiguous(), w1.t().contiguous())   # W2^T in the W1 slot, W1^T in the W2 slot
+        dpre = torch.empty((M, FF), device=dev, dtype=torch.bfloat16)
+        dx1 = ops.ffn_bwd_dx(dz, pkb, bits, dpre=dpre)
+        dx1_b = ops.ffn_bwd_dx(dz, pkb, bits)              # the instance without the dpre output
+        mask = (h0.float() > 0)
+        dh_ref = (dz.float() @ w2.float()) * mask
+        _close(dpre, dh_ref, 1e-2, 1e-2, "dpre")
+        assert torch.equal(dpre.float() != 0, (dh_ref.bfloat16().float() != 0) & mask) or \
+            float(((dpre.float() != 0) != ((dh_ref != 0) & mask)).float().mean()) < 1e-5   # the mask itself: exact (up to dH == 0)
+        dx_ref = dz.float() + dpre.float() @ w1.float()
+        _close(dx1, dx_ref, 1e-2, 2e-2, "dx1")
+        assert torch.equal(dx1, dx1_b)
+        # and against the two-GEMM path it replaces
+        dhid = ops.gemm_nt(dz, w2.t().contiguous(), epilogue=ops.EPI_RELUMASK, aux=h0)
+        dx_two = ops.gemm_nt(dhid, w1.t().contiguous(), epilogue=ops.EPI_RESID, aux=dz)
+        assert float((dpre.float() - dhid.float()).abs().max()) <= 2e-2 * float(dhid.float().abs().max())
+        assert float((dx1.float() - dx_two.float()).abs().max()) <= 3e-2 * float(dx_two.float().abs().max())
+
+
 @pytest.mark.parametrize("T,D", [(1000, 192), (333, 384), (70, 768), (5, 1024)])
 def test_layernorm_fwd_bwd(T, D):
     from chadavit_amd import ops
@@ -211,7 +253,7 @@ def _attn_ref(qkv, cu, H):
 
 @pytest.mark.parametrize("nch,p,D,H", [([3, 1, 10, 5], 196, 192, 2), ([1, 2], 36, 192, 2), ([2, 1, 1], 36, 384, 2),
                                        ([1], 4, 64, 2), ([3, 2], 36, 128, 2), ([1, 3], 196, 384, 2), ([2, 1], 36, 768, 2),
-                                       ([1, 2], 196, 768, 2)])
+                                       ([1, 2], 196, 768, 2), ([2, 3], 36, 192, 12), ([1, 2], 196, 192, 12)])
 def test_attention_fwd_bwd(nch, p, D, H):
     from chadavit_amd import ops
     from chadavit_amd.ragged import RaggedBatch

@@ -508,14 +508,16 @@ def test_attn_probs_ragged_matches_softmax():
             assert float((prs[i] - ref).abs().max()) <= 2e-6
 
 
-def test_backward_through_all_tokens_output_vs_oracle():
+@pytest.mark.parametrize("num_heads", [None, 12])
+def test_backward_through_all_tokens_output_vs_oracle(num_heads):
     """return_all_tokens=True (chada_vit.py:283-287) is differentiable on the HIP path: gradients of a linear functional of the
     patch-token output vs autograd through the oracle on the same weights / inputs (per-tensor cosine >= 0.99, global
-    grad-norm within 5 %)."""
+    grad-norm within 5 %).  num_heads = 12 is the reference's DEFAULT constructor (chada_vit.py:138-139: 12 heads, dh = 16,
+    final LayerNorm eps 1e-5) -- fine-tuning a notebook-constructed model runs the widened-head attention backward."""
     from chadavit_amd.data.channels_strategies import one_channel_collate_fn
     dev = _dev()
     D = 192
-    m = _backbone(D, 61, dev, return_all_tokens=True)
+    m = _backbone(D, 61, dev, return_all_tokens=True, num_heads=num_heads)
     imgs = P.make_images([2, 1, 3], [96], seed=62)
     crops, labels, ncl = one_channel_collate_fn(imgs)
     x = crops if isinstance(crops, torch.Tensor) else crops[0]
@@ -524,7 +526,7 @@ def test_backward_through_all_tokens_output_vs_oracle():
     wgt = P.tensor(tuple(out.shape), "alltok.w", 1.0, seed=63)
     (out * wgt.to(dev)).sum().backward()
     sd = {k: v.clone().requires_grad_(True) for k, v in P.fill_state_dict(P.backbone_shapes(D), seed=61).items()}
-    ref = R.backbone_ragged(sd, x, nch, return_all_tokens=True)
+    ref = R.backbone_ragged(sd, x, nch, return_all_tokens=True, **({} if num_heads is None else {"nheads": num_heads, "final_eps": 1e-5}))
     assert tuple(ref.shape) == tuple(out.shape)
     assert _cos(out.detach(), ref.detach()) >= 0.999
     (ref * wgt).sum().backward()

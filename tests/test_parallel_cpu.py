@@ -213,3 +213,19 @@ def test_token_balanced_sampler():
     with pytest.raises(ValueError):
         balanced_partition([1.0] * 10, 4)
     assert image_cost(10) / image_cost(1) > 15
+
+
+def test_bench_mixed_channel_batches_are_token_balanced_across_ranks():
+    """bench.py shards ONE seeded global batch of a 1-10 channel workload with data/sampler.py's token-balanced partition:
+    equal image counts per rank, per-rank token totals within 2 % (an independent draw per rank spreads them by tens of %)."""
+    import bench
+    from chadavit_amd.data.sampler import balanced_partition, image_cost
+    for world in (2, 4, 8):
+        for B in (32, 128):
+            g = bench.channel_list("1-10", B * world, seed=1000)
+            parts = balanced_partition([image_cost(c) for c in g], world)
+            assert sorted(i for p in parts for i in p) == list(range(B * world)) and all(len(p) == B for p in parts)
+            tokens = [sum(1 + g[i] * 196 for i in p) for p in parts]
+            assert max(tokens) / min(tokens) - 1.0 <= 0.02, (world, B, tokens)
+        naive = [sum(1 + c * 196 for c in bench.channel_list("1-10", 32, seed=1000 + r)) for r in range(world)]
+        assert max(naive) / min(naive) - 1.0 > 0.02  # what the sampler is there to avoid
