@@ -164,7 +164,6 @@ def ffn_pack(w1, w2, packed=None):
     return packed
 
 
-@_timed(lambda x, packed, b1, b2, *a, **k: ("ffn_fwd", x.shape[0], x.shape[1], (packed.numel() // 12288 - 1) * 32, k.get("h") is not None))
 def relu_bits_buffer(M, FF, device):
     """Caller-owned buffer for the ReLU pattern the fused forward records for the backward (M * FF / 8 bytes)."""
     n = int(lib().chadavit_relu_bits_bytes(c_int(M), c_int(FF)))
@@ -193,6 +192,7 @@ def ffn_bwd_dx(dz, packed_bwd, relu_bits, dx1=None, dpre=None):
     return dx1
 
 
+@_timed(lambda x, packed, b1, b2, *a, **k: ("ffn_fwd", x.shape[0], x.shape[1], (packed.numel() // 12288 - 1) * 32, k.get("h") is not None))
 def ffn_fwd(x, packed, b1, b2, resid=None, out=None, h=None, rows_per_wave=32, relu_bits=None):
     """out = resid + b2 + relu(x W1^T + b1) W2^T in one kernel; `h` (M, FF) receives relu(.) when given, `relu_bits` its sign
     pattern (relu_bits_buffer)."""
