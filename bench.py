@@ -34,6 +34,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, MI355X (guides/MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
+PEAK_MXFP8_TFLOPS = 5000.0  # dense MX-scaled fp8 MFMA (same guide)
 
 WORKLOADS = {
     # name: (embed_dim, channels spec, n_global, n_local, prototypes, per-GPU batch)
@@ -43,9 +44,12 @@ WORKLOADS = {
                  n_local=0, P=4096, batch=4),
     "cfg3": dict(desc="ChAda-ViT-Small/16, variable 1-10 channel, DINO 2 global + 8 local crops", D=384, channels="1-10",
                  n_global=2, n_local=8, P=4096, batch=128),
-    "cfg5": dict(desc="ChAda-ViT-Base/16, 10-channel 224x224 (max-token stress), DINO 2 global + 8 local crops, bf16 weights "
-                      "(the fp8 weight path of BASELINE configs[4] is not built)", D=768, channels="10", n_global=2, n_local=8,
-                 P=4096, batch=32),
+    "cfg5": dict(desc="ChAda-ViT-Base/16, 10-channel 224x224 (max-token stress), DINO 2 global + 8 local crops, fp8 weight path "
+                      "(encoder nn.Linear forwards on the MX-scaled fp8 MFMA: OCP-MX e4m3 weights and input activations, fp32 "
+                      "accumulate; attention / LayerNorm / backward bf16)", D=768, channels="10", n_global=2, n_local=8,
+                 P=4096, batch=32, weight_dtype="fp8"),
+    "cfg5-bf16": dict(desc="ChAda-ViT-Base/16, 10-channel 224x224, DINO 2 global + 8 local crops, bf16 weights (comparison run for "
+                           "cfg5)", D=768, channels="10", n_global=2, n_local=8, P=4096, batch=32),
 }
 
 
@@ -99,7 +103,7 @@ def make_cfg(wl):
     return AttrDict({
         "method": "dino",
         "backbone": {"name": "vit_channels", "kwargs": {"embed_dim": wl["D"], "patch_size": 16, "return_all_tokens": False,
-                                                        "max_number_channels": 10}},
+                                                        "max_number_channels": 10, "weight_dtype": wl.get("weight_dtype", "bf16")}},
         "data": {"dataset": "synthetic", "num_classes": 10, "max_img_channels": 10, "img_channels": 1,
                  "num_large_crops": wl["n_global"], "num_small_crops": wl["n_local"]},
         "channels_strategy": "multi_channels", "mixed_channels": True, "weights_init": "random", "max_epochs": 100,
@@ -292,6 +296,16 @@ def replay_launches(counts, nch, wl, dev, reps=10):
             aux_out = torch.empty((M, N), device=dev, dtype=bf) if epi == 2 else None
             o = torch.empty((M, N), device=dev, dtype=f32 if o32 else bf)
             fn = lambda: ops.gemm_nt(x, w, out=o, bias=bias, epilogue=epi, aux=aux, aux_out=aux_out, out_fp32=o32)
+        elif name == "gemm_nt_mx8":
+            _, M, N, K, epi = key
+            xq = torch.randint(0, 120, (M, K), device=dev, dtype=torch.uint8)
+            wq = torch.randint(0, 120, (N, K), device=dev, dtype=torch.uint8)
+            xs_ = torch.full((K // 32, M), 120, device=dev, dtype=torch.uint8)
+            ws_ = torch.full((K // 32, N), 120, device=dev, dtype=torch.uint8)
+            bias = torch.zeros(N, device=dev)
+            aux = torch.randn((M, N), device=dev).to(bf) if epi == 3 else None
+            o = torch.empty((M, N), device=dev, dtype=bf)
+            fn = lambda: ops.gemm_nt_mx8(xq, xs_, wq, ws_, bias=bias, epilogue=epi, aux=aux, out=o)
         elif name == "ffn_fwd":
             _, M, D_, FF_, wh = key
             x = torch.randn((M, D_), device=dev).to(bf)
@@ -511,7 +525,8 @@ def main():
         out = {
             "metric": "images/sec ChAda-ViT DINO multi-crop pretrain (whole training step)",
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "fp8-weights (MX e4m3 x e4m3 forward GEMMs, fp32 accumulate; bf16 elsewhere)" if wl.get("weight_dtype") == "fp8" else "bf16",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {wl['desc']}, bf16 storage / fp32 accumulate, {B} images per GPU, "
                                    f"head 2048/256/{wl['P']}, AdamW, reference-parity crop semantics",
@@ -534,8 +549,11 @@ def main():
                 tl = sum(1 + c * p96 for c in nch) * wl["n_local"]
                 sumsq[tl] = sum((1 + c * p96) ** 2 for c in nch) * wl["n_local"]
             name = key[0]
+            peak_tf = PEAK_BF16_TFLOPS
             if name == "gemm_nt":
                 flops, bound = 2.0 * key[1] * key[2] * key[3], "mfma"
+            elif name == "gemm_nt_mx8":
+                flops, bound, peak_tf = 2.0 * key[1] * key[2] * key[3], "mfma", PEAK_MXFP8_TFLOPS
             elif name == "gemm_tn":
                 flops, bound = 2.0 * key[1] * key[2] * key[3], "mfma"
             elif name in ("ffn_fwd", "ffn_ln_fwd"):
@@ -552,8 +570,8 @@ def main():
                 flops, bound = None, "hbm"
             if bound == "mfma":
                 ach = flops / (st["avg_us"] * 1e-6) / 1e12
-                roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None}
+                roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak_tf, "unit": "TFLOP/s",
+                        "frac": round(ach / peak_tf, 4), "traffic": None}
                 if name == "gemm_nt":  # at D=192 a stand-alone GEMM is below machine balance: HBM is the roof that binds
                     M_, N_, K_, epi_ = key[1], key[2], key[3], key[4]
                     nbytes = 2.0 * (M_ * K_ + N_ * K_ + M_ * N_ * (2 if epi_ in (3, 4, 5) else 1))

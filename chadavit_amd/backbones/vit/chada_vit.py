@@ -107,6 +107,10 @@ class ChAdaViT(nn.Module):
         # is the one checked against the oracle)
         self.fused_min_rows = FUSED_FFN_MIN_ROWS
         self._dw_stream = None
+        # "bf16" (default) or "fp8": the block's four nn.Linear forwards (in_proj, out_proj, linear1, linear2) on the MX-scaled fp8
+        # MFMA -- weights AND their input activations quantised to OCP-MX e4m3 (BASELINE.json configs[4], ChAda-ViT-Base); the
+        # backward keeps bf16 operands.  Needs embed_dim % 128 == 0.
+        self.weight_dtype = "bf16"
         self._capture_blocks = None  # tests: {block index: None} -> filled with that block's output (packed rows) by the forward
 
     @staticmethod
@@ -263,6 +267,18 @@ def _tokenize(m: ChAdaViT, flat: FlatParams, x, rb: RaggedBatch, pos_patch, add_
     return tokens, patches
 
 
+def _linear(m: ChAdaViT, flat: FlatParams, xb, wname: str, bias, epilogue=ops.EPI_NONE, aux=None):
+    """epilogue(xb W^T + bias): bf16 MFMA GEMM, or -- weight_dtype "fp8" -- OCP-MX fp8 operands on the scaled MFMA."""
+    if m.weight_dtype == "fp8":
+        n, k = flat.shapes[wname]
+        if n % 128 == 0 and k % 128 == 0 and epilogue in (ops.EPI_NONE, ops.EPI_RELU, ops.EPI_RESID):
+            wq, ws = flat.mx8(wname)
+            xq, xs = ops.mx8_quantize(xb)
+            return ops.gemm_nt_mx8(xq, xs, wq, ws, bias=bias, epilogue=epilogue, aux=aux)
+        raise RuntimeError(f"weight_dtype='fp8': {wname} {n}x{k} is not a multiple of 128 (embed_dim must be)")
+    return ops.gemm_nt(xb, flat.w(wname), bias=bias, epilogue=epilogue, aux=aux)
+
+
 def _block_fwd(m: ChAdaViT, flat: FlatParams, i: int, x, rb: RaggedBatch, save: bool, h=None, st=None, qkv=None):
     """One post-norm block.  `h` = LN1(x) may come precomputed (with its stats in st[0:2]) from the previous block's fused
     norm2 -> next-norm1 pass; the block in turn returns the NEXT block's h the same way."""
@@ -277,13 +293,12 @@ def _block_fwd(m: ChAdaViT, flat: FlatParams, i: int, x, rb: RaggedBatch, save: 
     if h is None and qkv is None:
         h = ops.layernorm_fwd(x, g1, b1, eps, mean=st[0] if save else None, rstd=st[1] if save else None)
     if qkv is None:  # (else: produced by the previous block's kernel)
-        qkv = ops.gemm_nt(h, flat.w(b + "self_attn.in_proj_weight"), bias=flat.f(b + "self_attn.in_proj_bias"))
+        qkv = _linear(m, flat, h, b + "self_attn.in_proj_weight", flat.f(b + "self_attn.in_proj_bias"))
     a, lse = ops.attn_fwd(qkv, rb.cu_seqlens, rb.work, H)
-    pk = flat.ffn_packed(b + "linear1.weight") if T >= m.fused_min_rows else None
+    pk = flat.ffn_packed(b + "linear1.weight") if (T >= m.fused_min_rows and m.weight_dtype != "fp8") else None
     pkp = flat.proj_ffn_packed(b + "linear1.weight") if pk is not None else None
     if pkp is None:
-        y = ops.gemm_nt(a, flat.w(b + "self_attn.out_proj.weight"), bias=flat.f(b + "self_attn.out_proj.bias"),
-                        epilogue=ops.EPI_RESID, aux=x)
+        y = _linear(m, flat, a, b + "self_attn.out_proj.weight", flat.f(b + "self_attn.out_proj.bias"), ops.EPI_RESID, x)
         x1 = ops.layernorm_fwd(y, g1, b1, eps, mean=st[2] if save else None, rstd=st[3] if save else None)
     last = i + 1 >= len(m.blocks)
     h_next = st_next = qkv_next = rbits = None
@@ -318,8 +333,8 @@ def _block_fwd(m: ChAdaViT, flat: FlatParams, i: int, x, rb: RaggedBatch, save: 
                                     ln_b=None if last else ln1n, stats_a=(st[4], st[5]) if save else None,
                                     stats_b=(st_next[0], st_next[1]) if (save and not last) else None)
     else:
-        hid = ops.gemm_nt(x1, flat.w(b + "linear1.weight"), bias=flat.f(b + "linear1.bias"), epilogue=ops.EPI_RELU)
-        z = ops.gemm_nt(hid, flat.w(b + "linear2.weight"), bias=flat.f(b + "linear2.bias"), epilogue=ops.EPI_RESID, aux=x1)
+        hid = _linear(m, flat, x1, b + "linear1.weight", flat.f(b + "linear1.bias"), ops.EPI_RELU)
+        z = _linear(m, flat, hid, b + "linear2.weight", flat.f(b + "linear2.bias"), ops.EPI_RESID, x1)
         if not last:
             x2, h_next = ops.layernorm_fwd2(z, ln2[0], ln2[1], ln1n[0], ln1n[1], ln2[2], ln1n[2],
                                             stats1=(st[4], st[5]) if save else None, stats2=(st_next[0], st_next[1]) if save else None)

@@ -116,6 +116,7 @@ class FlatParams:
         if pkb_desc:
             for i, w1 in enumerate(self._pk_src):
                 self._pkb[w1] = self._pkb_buf[pkb_desc[3 * i + 2]:pkb_desc[3 * i + 2] + nb]
+        self._mx8: Dict[str, Tuple[int, torch.Tensor, torch.Tensor]] = {}
         self._cast_version = None
         self._cast_version_t = None
         self._manual_version = 0
@@ -151,6 +152,17 @@ class FlatParams:
 
     def packed_has_next_qkv(self, w1_name: str) -> bool:
         return w1_name in self._pk_has_qkv
+
+    def mx8(self, name: str) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(e4m3 bytes (rows, cols), E8M0 scales (cols/32, rows)) of a 2-D weight: the OCP-MX fp8 copy the fp8 weight path multiplies
+        (ops.gemm_nt_mx8), quantised from the bf16 shadow once per parameter version."""
+        ver = self._cast_version
+        hit = self._mx8.get(name)
+        if hit is None or hit[0] != ver:
+            wq, ws = ops.mx8_quantize(self.w(name), q=hit[1] if hit else None, scales=hit[2] if hit else None)
+            hit = (ver, wq, ws)
+            self._mx8[name] = hit
+        return hit[1], hit[2]
 
     def f(self, name: str) -> torch.Tensor:
         return self.view(self.flat, name)

@@ -236,6 +236,12 @@ class DINO(_Base):
         # ---- momentum pieces (base.py:1005-1044)
         self.momentum_backbone: nn.Module = self.base_model(cfg.method, pretrained=False, **kwargs)
         initialize_momentum_params(self.backbone, self.momentum_backbone)
+        # build-side option (not a reference key): backbone.kwargs.weight_dtype = "fp8" runs the encoder's nn.Linear forwards of both
+        # networks on the MX-scaled fp8 MFMA (BASELINE.json configs[4]); the factory ignores unknown kwargs as the reference's does
+        wdt = omegaconf_select(cfg, "backbone.kwargs.weight_dtype", "bf16")
+        if wdt not in ("bf16", "fp8"):
+            raise RuntimeError(f"backbone.kwargs.weight_dtype must be 'bf16' or 'fp8', got {wdt}")
+        self.backbone.weight_dtype = self.momentum_backbone.weight_dtype = wdt
         self.momentum_classifier = None
         self.momentum_updater = MomentumUpdater(cfg.momentum.base_tau, cfg.momentum.final_tau)
         # ---- DINO pieces (dino.py:133-178)

@@ -265,6 +265,18 @@ int chadavit_clip_tensors(float* grads, const long long* offsets, const long lon
                           void* stream);
 int chadavit_sum_rows_f32(const float* x, float* out, int rows, int cols, float scale, void* stream);
 
+/* ---- fp8 weight path (BASELINE.json configs[4]: ChAda-ViT-Base) -------------------------------------------------------------
+ * OCP MX fp8: e4m3fn elements + one E8M0 power-of-two scale per 32 consecutive k of a row (the form gfx950's
+ * v_mfma_scale_f32_16x16x128_f8f6f4 multiplies at twice the bf16 MFMA rate).  Replaces the nn.Linear forwards of the encoder block
+ * (src/backbones/vit/chada_vit.py:95-116) when ChAdaViT.weight_dtype == "fp8".
+ * chadavit_mx8_quantize: x bf16 [R, K] (row stride ldx) -> q [R, K] e4m3 bytes (16-byte aligned), scales [K/32, R] E8M0 bytes;
+ *   relu != 0 applies max(x, 0) first (the FFN's hidden activation).  K % 32 == 0. */
+int chadavit_mx8_quantize(const chada_bf16* x, int ldx, void* q, void* scales, int R, int K, int relu, void* stream);
+/* Out[M,N] (bf16) = epilogue(deq(Xq, xs) deq(Wq, ws)^T + bias); epilogue 0 = none, 1 = ReLU, 3 = + aux (bf16 [M, N], ld ldaux).
+ * N % 128 == 0, K % 128 == 0. */
+int chadavit_gemm_nt_mx8(const void* Xq, const void* xs, const void* Wq, const void* ws, chada_bf16* Out, int ldo, int M, int N, int K,
+                         const float* bias, int epilogue, const chada_bf16* aux, int ldaux, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -642,3 +642,65 @@ def test_fused_ffn_layernorm_tail(M, save, two):
         assert d2.max().item() <= 3.2e-2 and (d2 > 0).float().mean().item() < 0.03
     else:
         assert hn is None
+
+
+def _mx_dequant(q, scales):
+    """(R, K) e4m3 bytes + (K/32, R) E8M0 bytes -> fp32 (R, K): the value the MFMA multiplies.  Power-of-two scaling done on the
+    CPU in float64 (exact); a GPU pow / ldexp is not."""
+    vals = q.cpu().view(torch.float8_e4m3fn).double()
+    ex = (scales.cpu().double() - 127.0).t().repeat_interleave(32, dim=1)   # (R, K)
+    return (vals * torch.pow(torch.tensor(2.0, dtype=torch.float64), ex)).float().to(q.device)
+
+
+@pytest.mark.parametrize("R,K", [(300, 768), (129, 2048), (5, 128)])
+def test_mx8_quantize(R, K):
+    """OCP-MX fp8 quantiser: per row and 32-k block one power-of-two scale 2^(floor(log2 amax) - 8) (+1 if the largest element would
+    exceed 448), elements rounded (RNE) to e4m3: checked against that definition evaluated exactly (float64, CPU), incl. an
+    all-zero block, a block at the 448 limit and the ReLU variant."""
+    from chadavit_amd import ops
+    dev = _dev()
+    x = (_rand((R, K), 91, 1.0) * torch.exp(_rand((R, 1), 92, 2.0))).bfloat16().to(dev)
+    x[0, :32] = 0
+    x[1, 32:64] = 448.0
+    two = torch.tensor(2.0, dtype=torch.float64)
+    for relu in (False, True):
+        q, sc = ops.mx8_quantize(x, relu=relu)
+        xf = (torch.relu(x.float()) if relu else x.float()).cpu().double()
+        blk = xf.view(R, K // 32, 32)
+        amax = blk.abs().amax(-1)
+        ex = torch.floor(torch.log2(amax.clamp_min(1e-300))) - 8
+        ex = torch.where(amax * torch.pow(two, -ex) > 448.0, ex + 1, ex)
+        ex = torch.where(amax > 0, ex, torch.zeros_like(ex))
+        assert torch.equal(sc.cpu().t().double() - 127, ex), float((sc.cpu().t().double() - 127 - ex).abs().max())
+        scaled = (blk * torch.pow(two, -ex)[..., None]).view(R, K).float()   # exact: a bf16 value times a power of two
+        ref = scaled.to(torch.float8_e4m3fn).float()
+        got = q.cpu().view(torch.float8_e4m3fn).float()
+        bad = got != ref
+        assert not bool(bad.any()), (int(bad.sum()), scaled[bad][:8].tolist(), got[bad][:8].tolist(), ref[bad][:8].tolist())
+        deq = _mx_dequant(q, sc).cpu().double()
+        err = (deq - xf).abs().view(R, K // 32, 32)
+        assert bool((err <= amax[..., None] * 2.0 ** -4 + 1e-30).all())   # half an e4m3 ulp of the block's largest binade
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 2304, 768), (257, 768, 768), (300, 2048, 768), (130, 768, 2048), (64, 128, 128)])
+def test_gemm_nt_mx8(M, N, K):
+    """MX-scaled fp8 MFMA GEMM vs fp32 torch on the DEQUANTISED operands (so only the accumulation order differs), all epilogues;
+    and vs the unquantised bf16 product within the quantisation noise (rel-L2 <= 6e-2: two e4m3 operands, 3 mantissa bits each)."""
+    from chadavit_amd import ops
+    dev = _dev()
+    x = _rand((M, K), 93, 1.0).bfloat16().to(dev)
+    w = (_rand((N, K), 94, 1.0) / math.sqrt(K)).bfloat16().to(dev)
+    bias = _rand((N,), 95, 0.5).to(dev)
+    aux = _rand((M, N), 96, 1.0).bfloat16().to(dev)
+    xq, xs = ops.mx8_quantize(x)
+    wq, ws = ops.mx8_quantize(w)
+    ref = _mx_dequant(xq, xs) @ _mx_dequant(wq, ws).t()
+    out = ops.gemm_nt_mx8(xq, xs, wq, ws)
+    _close(out, ref, 1e-2, 1e-2, "none")
+    out = ops.gemm_nt_mx8(xq, xs, wq, ws, bias=bias, epilogue=ops.EPI_RELU)
+    _close(out, torch.relu(ref + bias), 1e-2, 1e-2, "relu")
+    out = ops.gemm_nt_mx8(xq, xs, wq, ws, bias=bias, epilogue=ops.EPI_RESID, aux=aux)
+    _close(out, ref + bias + aux.float(), 1e-2, 2e-2, "resid")
+    exact = x.float() @ w.float().t()
+    rel = float((ref - exact).norm() / exact.norm())
+    assert rel <= 6e-2, rel

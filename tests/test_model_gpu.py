@@ -115,6 +115,56 @@ def test_dino_loss_module_vs_golden(name):
     assert abs(lf.center.double().sum().item() - float(g["center_new_sum"])) <= 1e-4 * (1 + abs(float(g["center_new_sum"])))
 
 
+def test_fp8_weight_path_vs_golden():
+    """BASELINE.json configs[4]: ChAda-ViT-Base with the encoder's nn.Linear forwards on the MX-scaled fp8 MFMA (weights and their
+    input activations in OCP-MX e4m3, fp32 accumulate; attention, LayerNorm, residuals and the whole backward in bf16 / fp32).
+    Tolerance of SURVEY 8(c) for this path: CLS cosine >= 0.99 vs the reference's fp32 output; DINO loss abs <= 5e-2."""
+    from chadavit_amd import ops
+    from chadavit_amd.data.channels_strategies import one_channel_collate_fn
+    from chadavit_amd.methods.dino import DINO
+    from chadavit_amd.trainer import Trainer
+    dev = _dev()
+    g = np.load(os.path.join(GOLDEN, "backbone_base.npz"))
+    D = int(g["D"])
+    m = _backbone(D, int(g["seed_w"]), dev)
+    m.weight_dtype = "fp8"
+    crops, labels, ncl = one_channel_collate_fn(P.make_images([int(c) for c in g["nch"]], [int(s) for s in g["sizes"]], seed=int(g["seed_x"])))
+    crops = crops if isinstance(crops, list) else [crops]
+    with torch.no_grad(), ops.LaunchProfiler() as prof:
+        cls = m(crops[0].to(dev), 0, ncl if isinstance(ncl[0], list) else [ncl])
+    keys = prof.summary()
+    assert sum(v["launches"] for k, v in keys.items() if k[0] == "gemm_nt_mx8") == 4 * 12   # the fp8 kernels really ran
+    ref = torch.from_numpy(g["cls0"])
+    assert _cos(cls, ref) >= 0.99, _cos(cls, ref)
+    print("fp8 backbone_base: CLS cosine", _cos(cls, ref), "rel-L2", _rel(cls, ref))
+    # ---- a whole training step (student fwd + bwd, teacher fwd, loss) against the reference's Base step golden
+    g = np.load(os.path.join(GOLDEN, "step_base_c10.npz"))
+    D, PR = int(g["D"]), int(g["P"])
+    cfg = _cfg(D, PR, int(g["n_large"]), 0)
+    cfg.backbone.kwargs.weight_dtype = "fp8"
+    model = DINO(cfg)
+    model.load_state_dict(build_sd(D, PR))
+    model = model.to(dev)
+    assert model.backbone.weight_dtype == model.momentum_backbone.weight_dtype == "fp8"
+    crops, labels, ncl = one_channel_collate_fn(P.make_images([int(c) for c in g["nch"]], [int(s) for s in g["sizes"]], seed=7))
+    tr = Trainer(max_epochs=10, steps_per_epoch=10)
+    tr.current_epoch = int(g["epoch"])
+    tr.attach(model)
+    model.current_epoch = int(g["epoch"])
+    model.on_train_epoch_start()
+    loss = model.training_step(([c.to(dev) for c in crops], labels.to(dev), ncl), 1)
+    loss.backward()
+    model.on_after_backward()
+    assert abs(loss.item() - float(g["loss"])) <= 5e-2, (loss.item(), float(g["loss"]))
+    named = dict(model.named_parameters())
+    tot_h = sum(named[str(n)].grad.double().norm().item() ** 2 for n in g["grad_names"]) ** 0.5
+    tot_r = float(np.sqrt((g["grad_norms"] ** 2).sum()))
+    print("fp8 step_base_c10: loss", loss.item(), "vs", float(g["loss"]), "grad norm", tot_h, "vs", tot_r)
+    assert abs(tot_h - tot_r) <= 0.15 * tot_r, (tot_h, tot_r)   # fp8 forward activations feed a bf16 backward
+    for key in ("backbone.norm.weight", "head.mlp.4.bias"):
+        assert _cos(named[key].grad, torch.from_numpy(g["grad::" + key])) >= 0.95, key
+
+
 def test_backbone_errors_and_surface():
     dev = _dev()
     m = _backbone(192, 1, dev)
