@@ -1,0 +1,215 @@
+"""Multi-crop augmentation on the GPU, emitting the collate layout the tokenizer consumes.
+
+Reference: `build_transform_pipeline` + `NCropAugmentation` + `one_channel_collate_fn`
+(src/data/pretrain_dataloader.py:132-154, 272-328; src/data/channels_strategies.py:31-85).  There every crop of every image goes
+through albumentations / OpenCV on a DataLoader worker, channel by channel for the jitter, and the collate function then stacks
+channels on the batch axis.  Here the host only DRAWS the random parameters (a few dozen numbers per image) and uploads the raw
+planes once; two HIP kernels per crop size produce the `(sum C, 1, S, S)` tensors directly:
+
+    chadavit_crop_resize : RandomResizedCrop / Resize (cv2.INTER_CUBIC) -> CustomColorJitter -> HorizontalFlip
+    chadavit_blur_finish : GaussianBlur (reflect-101) -> Solarize -> Normalize          (skipped when none of them fires)
+
+Random draws follow the order in which albumentations 1.3.1's Compose consumes Python's `random` / numpy's global RNG for this
+pipeline (every transform draws `random.random() < p` first; RandomResizedCrop: area, log-ratio, corner; CustomColorJitter:
+np.random.uniform shifts then gammas; GaussianBlur: kernel size, sigma; Solarize: threshold); that order is restated from the
+pinned version's published source and is NOT verifiable here (albumentations is absent) -- statistics, not streams, are what the
+training contract needs.  ToGray / Equalize of the reference pipeline require 3-channel / uint8 images and are rejected.
+"""
+from __future__ import annotations
+
+import math
+import random
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from .. import ops
+
+
+@dataclass
+class CropSpec:
+    """One entry of the reference's augmentation list (cfg.augmentations[i]): crop_size, rrc, color_jitter, gaussian_blur,
+    solarization, horizontal_flip, normalize, num_crops."""
+    crop_size: int = 224
+    num_crops: int = 2
+    rrc_enabled: bool = True
+    crop_min_scale: float = 0.25
+    crop_max_scale: float = 1.0
+    jitter_prob: float = 0.0
+    int_min_shift: float = -0.3
+    int_max_shift: float = 0.3
+    gamma_min: float = 0.5
+    gamma_max: float = 1.5
+    blur_prob: float = 0.0
+    blur_limit: Tuple[int, int] = (3, 7)
+    sigma_limit: Tuple[float, float] = (0.1, 2.0)
+    solarize_prob: float = 0.0
+    solarize_threshold: float = 128.0   # albumentations' default (a uint8 scale: never fires on [0, 1] floats)
+    solarize_max: float = 1.0           # MAX_VALUES_BY_DTYPE[float32]
+    flip_prob: float = 0.0
+    normalize: Optional[Tuple[Sequence[float], Sequence[float], float]] = None   # (mean per channel, std per channel, max_pixel_value)
+    ratio: Tuple[float, float] = (3.0 / 4.0, 4.0 / 3.0)
+
+    @staticmethod
+    def from_cfg(aug) -> "CropSpec":
+        """From one node of the reference's `augmentations` cfg list (keys of pretrain_dataloader.py:232-255)."""
+        g = lambda node, key, default: (node.get(key, default) if hasattr(node, "get") else getattr(node, key, default))
+        if g(g(aug, "grayscale", {}), "prob", 0) or g(g(aug, "equalization", {}), "prob", 0):
+            raise RuntimeError("ToGray / Equalize need 3-channel / uint8 images: not part of the channel-adaptive float path")
+        cj, rrc = g(aug, "color_jitter", {}), g(aug, "rrc", {})
+        norm = g(aug, "normalize", None)
+        return CropSpec(crop_size=g(aug, "crop_size", 224), num_crops=g(aug, "num_crops", 1), rrc_enabled=bool(g(rrc, "enabled", True)),
+                        crop_min_scale=g(rrc, "crop_min_scale", 0.08), crop_max_scale=g(rrc, "crop_max_scale", 1.0),
+                        jitter_prob=g(cj, "prob", 0.0), int_min_shift=g(cj, "int_min_shift", -0.3), int_max_shift=g(cj, "int_max_shift", 0.3),
+                        gamma_min=g(cj, "gamma_min", 0.5), gamma_max=g(cj, "gamma_max", 1.5),
+                        blur_prob=g(g(aug, "gaussian_blur", {}), "prob", 0.0), solarize_prob=g(g(aug, "solarization", {}), "prob", 0.0),
+                        flip_prob=g(g(aug, "horizontal_flip", {}), "prob", 0.0),
+                        normalize=(g(aug, "mean", None), g(aug, "std", None), 255.0) if norm and g(aug, "mean", None) is not None else None)
+
+
+def rrc_box(H: int, W: int, scale, ratio, rng: random.Random) -> Tuple[int, int, int, int]:
+    """(y0, x0, h, w): albumentations 1.3.1 RandomResizedCrop parameter draw (10 attempts, central fallback)."""
+    area = H * W
+    for _ in range(10):
+        target_area = rng.uniform(*scale) * area
+        aspect = math.exp(rng.uniform(math.log(ratio[0]), math.log(ratio[1])))
+        w = int(round(math.sqrt(target_area * aspect)))
+        h = int(round(math.sqrt(target_area / aspect)))
+        if 0 < w <= W and 0 < h <= H:
+            i, j = rng.randint(0, H - h), rng.randint(0, W - w)
+            return int((H - h) * (i * 1.0 / (H - h + 1e-10))), int((W - w) * (j * 1.0 / (W - w + 1e-10))), h, w
+    in_ratio = W / H
+    if in_ratio < min(ratio):
+        w, h = W, int(round(W / min(ratio)))
+    elif in_ratio > max(ratio):
+        h, w = H, int(round(H * max(ratio)))
+    else:
+        w, h = W, H
+    i, j = (H - h) // 2, (W - w) // 2
+    return int((H - h) * (i * 1.0 / (H - h + 1e-10))), int((W - w) * (j * 1.0 / (W - w + 1e-10))), h, w
+
+
+def gaussian_taps(ksize: int, sigma: float) -> np.ndarray:
+    """7 centred taps of cv2.getGaussianKernel(ksize, sigma) (zero-padded), float32."""
+    i = np.arange(ksize, dtype=np.float64) - (ksize - 1) / 2.0
+    k = np.exp(-(i * i) / (2.0 * sigma * sigma))
+    out = np.zeros(7, dtype=np.float32)
+    out[:ksize] = (k / k.sum()).astype(np.float32)
+    return out
+
+
+@dataclass
+class CropParams:
+    """Everything random about one crop of one batch (host side), for replay / tests."""
+    boxes: List[Tuple[int, int, int, int]] = field(default_factory=list)     # per image (y0, x0, h, w)
+    shifts: List[Optional[np.ndarray]] = field(default_factory=list)         # per image: (C,) or None
+    gammas: List[Optional[np.ndarray]] = field(default_factory=list)
+    blurs: List[Optional[Tuple[int, float]]] = field(default_factory=list)   # per image (ksize, sigma) or None
+    solarize: List[Optional[float]] = field(default_factory=list)            # per image threshold or None
+    flips: List[bool] = field(default_factory=list)
+
+
+class DeviceMultiCropPipeline:
+    def __init__(self, specs: Sequence[CropSpec], device, seed: int = 0):
+        self.specs = list(specs)
+        self.device = torch.device(device)
+        self.rng = random.Random(seed)            # stands for Python's global `random` (albumentations' source of randomness)
+        self.np_rng = np.random.RandomState(seed)  # stands for numpy's global RNG (CustomColorJitter draws from it)
+        self.last_params: List[CropParams] = []
+
+    @property
+    def num_crops(self) -> int:
+        return sum(s.num_crops for s in self.specs)
+
+    def _draw(self, spec: CropSpec, shapes: Sequence[Tuple[int, int, int]]) -> CropParams:
+        p = CropParams()
+        for (C, H, W) in shapes:
+            self.rng.random()  # RandomResizedCrop / Resize: p = 1.0, the draw still happens (BasicTransform.__call__)
+            p.boxes.append(rrc_box(H, W, (spec.crop_min_scale, spec.crop_max_scale), spec.ratio, self.rng) if spec.rrc_enabled else (0, 0, H, W))
+            if spec.jitter_prob and self.rng.random() < spec.jitter_prob:
+                p.shifts.append(self.np_rng.uniform(spec.int_min_shift, spec.int_max_shift, C))
+                p.gammas.append(self.np_rng.uniform(spec.gamma_min, spec.gamma_max, C))
+            else:
+                p.shifts.append(None); p.gammas.append(None)
+            if spec.blur_prob and self.rng.random() < spec.blur_prob:
+                k = self.rng.randrange(spec.blur_limit[0], spec.blur_limit[1] + 1)
+                if k != 0 and k % 2 != 1:
+                    k = (k + 1) % (spec.blur_limit[1] + 1)
+                p.blurs.append((k, self.rng.uniform(*spec.sigma_limit)))
+            else:
+                p.blurs.append(None)
+            if spec.solarize_prob and self.rng.random() < spec.solarize_prob:
+                p.solarize.append(self.rng.uniform(spec.solarize_threshold, spec.solarize_threshold))
+            else:
+                p.solarize.append(None)
+            p.flips.append(bool(spec.flip_prob and self.rng.random() < spec.flip_prob))
+        return p
+
+    def __call__(self, images: Sequence[np.ndarray], labels: Optional[Sequence[int]] = None, params: Optional[List[CropParams]] = None):
+        """images: per sample a float32 array (C_i, H_i, W_i) (channel planes; sizes may differ between samples).
+        Returns what `one_channel_collate_fn` returns for the same batch: (crops, labels, list_num_channels) with
+        crops[k] (sum C, 1, S_k, S_k) fp32 on the device."""
+        planes = [np.ascontiguousarray(im, dtype=np.float32) for im in images]
+        shapes = [tuple(im.shape) for im in planes]
+        nch = [s[0] for s in shapes]
+        offs, tot = [], 0
+        for (C, H, W) in shapes:
+            offs.append(tot)
+            tot += C * H * W
+        host = torch.empty(tot, dtype=torch.float32).pin_memory() if self.device.type == "cuda" else torch.empty(tot, dtype=torch.float32)
+        for o, im in zip(offs, planes):
+            host[o:o + im.size] = torch.from_numpy(im.reshape(-1))
+        src = host.to(self.device, non_blocking=True)
+        crops, used = [], []
+        it = iter(params) if params is not None else None
+        for spec in self.specs:
+            for _ in range(spec.num_crops):
+                cp = next(it) if it is not None else self._draw(spec, shapes)
+                used.append(cp)
+                crops.append(self._run_crop(spec, cp, src, shapes, offs))
+        self.last_params = used
+        lab = torch.as_tensor(list(labels) if labels is not None else [-1] * len(planes), dtype=torch.int64, device=self.device)
+        if len(crops) == 1:   # one_channel_collate_fn returns a bare tensor / list for a single crop (channels_strategies.py:81)
+            return crops[0], lab, nch
+        return crops, lab, [list(nch) for _ in crops]
+
+    def _run_crop(self, spec: CropSpec, cp: CropParams, src, shapes, offs) -> torch.Tensor:
+        S = spec.crop_size
+        desc, shift, gamma, fin = [], [], [], []
+        any_jit = any(s is not None for s in cp.shifts)
+        any_fin = spec.normalize is not None or any(b is not None for b in cp.blurs) or any(t is not None for t in cp.solarize)
+        for i, (C, H, W) in enumerate(shapes):
+            y0, x0, h, w = cp.boxes[i]
+            for c in range(C):
+                desc.append([offs[i] + c * H * W, H, W, x0, y0, w, h, 1 if cp.flips[i] else 0])
+                if any_jit:
+                    shift.append(0.0 if cp.shifts[i] is None else float(cp.shifts[i][c]))
+                    gamma.append(-1.0 if cp.gammas[i] is None else float(cp.gammas[i][c]))
+                if any_fin:
+                    row = np.zeros(12, dtype=np.float32)
+                    if cp.blurs[i] is not None and cp.blurs[i][0] > 1:
+                        k, sg = cp.blurs[i]
+                        if k > 7:
+                            raise RuntimeError("GaussianBlur kernel sizes above 7 are not supported on the device path")
+                        row[0] = k
+                        row[1:8] = gaussian_taps(k, sg)
+                    row[8] = np.inf if cp.solarize[i] is None else cp.solarize[i]
+                    row[9] = spec.solarize_max
+                    if spec.normalize is not None:
+                        mean, std, mpv = spec.normalize
+                        row[10] = float(mean[c % len(mean)]) * mpv
+                        row[11] = 1.0 / (float(std[c % len(std)]) * mpv)
+                    else:
+                        row[10], row[11] = 0.0, 1.0
+                    fin.append(row)
+        dev = self.device
+        d = torch.tensor(desc, dtype=torch.int64).to(dev)
+        if any_jit:   # gamma = -1 marks the channel images whose sample did not draw the jitter (no clamp for them)
+            out = ops.crop_resize(src, d, S, torch.tensor(shift, dtype=torch.float32).to(dev), torch.tensor(gamma, dtype=torch.float32).to(dev))
+        else:
+            out = ops.crop_resize(src, d, S)
+        if any_fin:
+            out = ops.blur_finish(out, torch.from_numpy(np.stack(fin)).to(dev))
+        return out

@@ -664,3 +664,33 @@ def gemm_nt_mx8(xq, xs, wq, ws, bias=None, epilogue=EPI_NONE, aux=None, out=None
                                     _ptr(bias), c_int(epilogue), _ptr(aux), c_int(aux.stride(0) if aux is not None else 0), _stream())
     _chk(rc, "chadavit_gemm_nt_mx8")
     return out
+
+
+# ---- device augmentation ---------------------------------------------------------------------------------------
+def crop_resize(src, desc, S, shift=None, gamma=None, out=None):
+    """src: packed fp32 source planes; desc (n, 8) int64 {offset, H, W, x0, y0, cw, ch, flip}; -> (n, 1, S, S) fp32 crops
+    (bicubic as cv2.INTER_CUBIC, optional per-channel jitter clamp(gamma (x + shift), 0, 1), optional h-flip)."""
+    _req(src, F32, "src"); _req(desc, I64, "desc")
+    n = desc.shape[0]
+    if desc.dim() != 2 or desc.shape[1] != 8:
+        raise RuntimeError("crop_resize: desc must be (n, 8) int64")
+    if out is None:
+        out = torch.empty((n, 1, S, S), device=src.device, dtype=F32)
+    _req(out, F32, "out")
+    if shift is not None:
+        _req(shift, F32, "shift"); _req(gamma, F32, "gamma")
+    _chk(lib().chadavit_crop_resize(_ptr(src), _ptr(desc), _ptr(shift), _ptr(gamma), _ptr(out), c_int(n), c_int(S), _stream()),
+         "chadavit_crop_resize")
+    return out
+
+
+def blur_finish(x, fin, out=None):
+    """GaussianBlur -> Solarize -> Normalize per channel image of x (n, 1, S, S); fin (n, 12) fp32 (see include/chadavit_hip.h)."""
+    _req(x, F32, "x"); _req(fin, F32, "fin")
+    n, S = x.shape[0], x.shape[-1]
+    if tuple(fin.shape) != (n, 12):
+        raise RuntimeError("blur_finish: fin must be (n, 12) fp32")
+    if out is None:
+        out = torch.empty_like(x)
+    _chk(lib().chadavit_blur_finish(_ptr(x), _ptr(fin), _ptr(out), c_int(n), c_int(S), _stream()), "chadavit_blur_finish")
+    return out

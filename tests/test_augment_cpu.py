@@ -1,0 +1,114 @@
+"""(f)2 data path, CPU side: the oracle's restatement of the cv2 / albumentations arithmetic (oracle/augment_ref.py) against
+independent implementations and closed forms, the host-side parameter draws, and the IDRCell100k-format reader.
+cv2 / albumentations are absent from the image: what is checked is the published algorithm, see the oracle's header."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import augment_ref as A
+
+
+def _img(h, w, seed):
+    return np.random.RandomState(seed).rand(h, w).astype(np.float32)
+
+
+@pytest.mark.parametrize("h,w,S", [(224, 224, 96), (150, 201, 224), (37, 53, 96), (224, 224, 224), (64, 48, 96), (300, 300, 224)])
+def test_resize_cubic_matches_torch_bicubic(h, w, S):
+    """torch's bicubic (align_corners=False, no antialias) is documented to match OpenCV's INTER_CUBIC: A = -0.75, half-pixel
+    centres, border taps clamped.  Independent implementation of the same published algorithm -> agreement up to the rounding of the
+    source coordinate (OpenCV forms it in double and casts, torch in float32: a few 1e-5 on [0, 1] images)."""
+    img = _img(h, w, 1)
+    ref = F.interpolate(torch.from_numpy(img)[None, None], size=(S, S), mode="bicubic", align_corners=False)[0, 0].numpy()
+    np.testing.assert_allclose(A.resize_cubic(img, S), ref, atol=6e-5, rtol=0)
+
+
+def test_cubic_closed_forms():
+    t = np.linspace(0, 1, 33, dtype=np.float32)
+    w = A.cubic_weights(t)
+    np.testing.assert_allclose(w.sum(-1), 1.0, atol=1e-6)                       # partition of unity: constants are reproduced
+    np.testing.assert_allclose(A.cubic_weights(np.float32(0.0)), [0, 1, 0, 0], atol=1e-7)   # interpolating at the nodes
+    np.testing.assert_allclose(w[:, ::-1], A.cubic_weights(1 - t), atol=1e-6)   # symmetric
+    np.testing.assert_allclose(A.cubic_weights(np.float32(0.5)), [-0.09375, 0.59375, 0.59375, -0.09375], atol=1e-7)  # A = -0.75
+    const = np.full((40, 56), 0.37, dtype=np.float32)
+    np.testing.assert_allclose(A.resize_cubic(const, 96), 0.37, atol=1e-6)
+    # integer upscale x2 of a delta: the response is the tap pattern at t = 0.25 / 0.75
+    d = np.zeros((9, 9), dtype=np.float32); d[4, 4] = 1
+    up = A.resize_cubic(d, 18)
+    w25, w75 = A.cubic_weights(np.float32(0.25)), A.cubic_weights(np.float32(0.75))
+    # output pixel 8: fx = 8.5 * 0.5 - 0.5 = 3.75 -> taps 2..5, weight of source 4 is w75[2]; pixel 9: fx = 4.25 -> taps 3..6, w25[1]
+    np.testing.assert_allclose(up[8, 8], w75[2] * w75[2], atol=1e-6)
+    np.testing.assert_allclose(up[9, 8], w25[1] * w75[2], atol=1e-6)
+    assert A.resize_cubic(d, 9) is not d and np.array_equal(A.resize_cubic(d, 9), d)   # same size: a copy
+
+
+def test_gaussian_blur_closed_forms():
+    from scipy import ndimage
+    for k, s in ((3, 0.1), (3, 0.8), (5, 1.3), (7, 2.0)):
+        g = A.gaussian_kernel1d(k, s)
+        assert abs(g.sum() - 1) < 1e-6 and np.allclose(g, g[::-1]) and g.argmax() == k // 2
+        img = _img(30, 41, k)
+        ref = ndimage.correlate1d(ndimage.correlate1d(img, g, axis=1, mode="mirror"), g, axis=0, mode="mirror")  # mirror = reflect-101
+        np.testing.assert_allclose(A.gaussian_blur(img, k, s), ref, atol=2e-6)
+        d = np.zeros((15, 15), dtype=np.float32); d[7, 7] = 1
+        np.testing.assert_allclose(A.gaussian_blur(d, k, s)[7 - k // 2:8 + k // 2, 7 - k // 2:8 + k // 2], np.outer(g, g), atol=1e-7)
+    np.testing.assert_allclose(A.gaussian_blur(np.full((9, 9), 2.5, np.float32), 7, 1.0), 2.5, atol=1e-5)
+
+
+def test_pointwise_steps():
+    x = np.array([[0.0, 0.2, 0.5, 0.9, 1.0]], dtype=np.float32)
+    np.testing.assert_allclose(A.solarize(x, 0.5), [[0.0, 0.2, 0.5, 0.1, 0.0]], atol=1e-7)
+    assert np.array_equal(A.solarize(x, 128.0), x)          # albumentations' default threshold on [0, 1] floats: no-op
+    np.testing.assert_allclose(A.normalize(x * 255, 0.5, 0.25), (x - 0.5) / 0.25, atol=1e-5)
+    np.testing.assert_allclose(A.color_jitter(x, 0.1, 2.0), np.clip(2.0 * (x + 0.1), 0, 1), atol=1e-7)
+    # the reference-owned jitter itself is pinned by tests/golden/jitter.npz (tests/test_oracle_golden.py)
+
+
+def test_rrc_parameter_draws():
+    """Host-side draws of the device pipeline == the oracle's restatement for the same seed; boxes are inside the image, the area
+    fraction is in `scale`, aspect ratio in [3/4, 4/3] up to integer rounding."""
+    from chadavit_amd.data.device_pipeline import rrc_box
+    r1, r2 = random.Random(5), random.Random(5)
+    for H, W in ((224, 224), (300, 180), (97, 131)):
+        for _ in range(50):
+            b1 = rrc_box(H, W, (0.25, 1.0), (3 / 4, 4 / 3), r1)
+            b2 = A.random_resized_crop_params(H, W, (0.25, 1.0), r2)
+            assert b1 == b2
+            y0, x0, h, w = b1
+            assert 0 <= y0 and y0 + h <= H and 0 <= x0 and x0 + w <= W and h > 0 and w > 0
+            assert 0.24 <= h * w / (H * W) <= 1.0 and 0.7 <= w / h <= 1.4
+
+
+def test_idrcell_reader(tmp_path):
+    """IDRCell100k format (custom_datasets.py:153-220): csv of (id, list of per-channel files under images/) -> HWC float32."""
+    from PIL import Image
+    from chadavit_amd.data.idrcell import IDRCell100K
+    root = tmp_path
+    os.makedirs(root / "images" / "exp1")
+    rs = np.random.RandomState(0)
+    rows, truth = [], []
+    for i, c in enumerate([3, 1, 5]):
+        paths, planes = [], []
+        for ch in range(c):
+            arr = rs.randint(0, 65535, size=(20 + i, 24), dtype=np.uint16) if ch % 2 == 0 else rs.randint(0, 255, size=(20 + i, 24), dtype=np.uint8)
+            rel = f"exp1/img{i}_ch{ch}.{'tif' if ch % 2 == 0 else 'png'}"
+            Image.fromarray(arr).save(root / "images" / rel)
+            paths.append(rel); planes.append(arr.astype(np.float32))
+        rows.append((f"id{i}", paths)); truth.append(np.stack(planes, 0))
+    with open(root / "train.csv", "w") as f:
+        for iid, paths in rows:
+            f.write(f'{iid},"{paths}"\n')
+    ds = IDRCell100K(root_dir=str(root), train=True)
+    assert len(ds) == 3 and ds.num_channels() == [3, 1, 5]
+    for i in range(3):
+        planes = ds.read_planes(i)
+        assert planes.dtype == np.float32 and np.array_equal(planes, truth[i])
+        img, label = ds[i]
+        assert label == -1 and img.shape == (20 + i, 24, len(rows[i][1])) and np.array_equal(img.transpose(2, 0, 1), truth[i])
+    seen = {}
+    ds2 = IDRCell100K(root_dir=str(root), train=True, transform=lambda image: seen.setdefault("shape", image.shape) and {"image": image})
+    out, _ = ds2[2]
+    assert seen["shape"] == (22, 24, 5)

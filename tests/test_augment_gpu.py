@@ -1,0 +1,83 @@
+"""(f)2 data path on the GPU: chadavit_amd.data.device_pipeline (HIP crop-resize / jitter / flip / blur / solarize / normalise
+kernels) against the oracle's restatement of the reference pipeline's arithmetic (oracle/augment_ref.py) on the same drawn
+parameters, and its output layout against the reference collate (A1)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import augment_ref as A
+from oracle import chada_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(seed=0):
+    rs = np.random.RandomState(seed)
+    shapes = [(3, 224, 224), (1, 150, 201), (5, 97, 131), (10, 224, 224), (2, 64, 48)]
+    return [rs.rand(*s).astype(np.float32) for s in shapes]
+
+
+def test_device_multicrop_matches_oracle_and_collate_layout():
+    from chadavit_amd.data.device_pipeline import CropSpec, DeviceMultiCropPipeline
+    dev = torch.device("cuda:0")
+    imgs = _batch()
+    specs = [CropSpec(crop_size=224, num_crops=2, crop_min_scale=0.25, crop_max_scale=1.0, jitter_prob=0.8, blur_prob=0.7, solarize_prob=0.5,
+                      solarize_threshold=0.6, flip_prob=0.5, normalize=([0.4, 0.5, 0.6], [0.2, 0.25, 0.3], 1.0)),
+             CropSpec(crop_size=96, num_crops=3, crop_min_scale=0.05, crop_max_scale=0.25, jitter_prob=0.8, blur_prob=0.5, flip_prob=0.5),
+             CropSpec(crop_size=224, num_crops=1, rrc_enabled=False)]   # plain Resize branch (pretrain_dataloader.py:292-299)
+    pipe = DeviceMultiCropPipeline(specs, dev, seed=3)
+    crops, labels, ncl = pipe(imgs, labels=[0, 1, 2, 3, 4])
+    assert len(crops) == 6 and [tuple(c.shape) for c in crops] == [(21, 1, 224, 224)] * 2 + [(21, 1, 96, 96)] * 3 + [(21, 1, 224, 224)]
+    assert ncl == [[3, 1, 5, 10, 2]] * 6 and labels.tolist() == [0, 1, 2, 3, 4]
+    drew = {"jit": 0, "blur": 0, "sol": 0, "flip": 0}
+    k = 0
+    for spec in specs:
+        for _ in range(spec.num_crops):
+            cp = pipe.last_params[k]
+            ref_planes = []
+            for i, im in enumerate(imgs):
+                for c in range(im.shape[0]):
+                    norm = None
+                    if spec.normalize is not None:
+                        mean, std, mpv = spec.normalize
+                        norm = (mean[c % 3], std[c % 3], mpv)
+                    ref_planes.append(A.augment_plane(im[c], spec.crop_size, cp.boxes[i],
+                                                      None if cp.shifts[i] is None else cp.shifts[i][c],
+                                                      None if cp.gammas[i] is None else cp.gammas[i][c], cp.flips[i], cp.blurs[i],
+                                                      cp.solarize[i], norm))
+                drew["jit"] += cp.shifts[i] is not None; drew["blur"] += cp.blurs[i] is not None
+                drew["sol"] += cp.solarize[i] is not None; drew["flip"] += cp.flips[i]
+            ref = np.stack(ref_planes)[:, None]
+            got = crops[k].cpu().numpy()
+            # solarize is discontinuous: a value within round-off of the threshold may land on the other side -> compare away from it
+            near = np.zeros_like(ref, dtype=bool)
+            if any(t is not None for t in cp.solarize):
+                near = np.abs(np.abs(got - ref)) > 0.05
+                assert near.mean() < 1e-4
+            scale = 1.0 if spec.normalize is None else 5.0
+            np.testing.assert_allclose(got[~near], ref[~near], atol=2e-5 * scale, rtol=0)
+            k += 1
+    assert all(v > 0 for v in drew.values()), drew   # every transform really fired somewhere
+    # same layout as the reference collate of per-image (C, S, S) crops (channels_strategies.py:31-85)
+    per_image = []
+    off = 0
+    for im in imgs:
+        per_image.append(([crops[j][off:off + im.shape[0], 0].cpu() for j in range(6)], 0))
+        off += im.shape[0]
+    cc, _, ncl2 = R.collate(per_image)
+    assert ncl2 == ncl and all(torch.equal(a, b.cpu()) for a, b in zip(cc, crops))
+
+
+def test_pipeline_feeds_the_training_step():
+    """Real-data shaped path end to end: raw planes -> device pipeline -> DINO.training_step (no host-side crop tensors)."""
+    from chadavit_amd.data.device_pipeline import CropSpec, DeviceMultiCropPipeline
+    from chadavit_amd.methods.dino import DINO
+    from chadavit_amd.trainer import Trainer
+    from tests.test_model_gpu import _cfg
+    dev = torch.device("cuda:0")
+    pipe = DeviceMultiCropPipeline([CropSpec(224, 2, jitter_prob=0.8, blur_prob=0.5, flip_prob=0.5),
+                                    CropSpec(96, 2, crop_min_scale=0.05, crop_max_scale=0.25, jitter_prob=0.8, flip_prob=0.5)], dev, seed=1)
+    model = DINO(_cfg(192, 4096, 2, 2)).to(dev)
+    tr = Trainer(max_epochs=2, steps_per_epoch=4).attach(model)
+    losses = [tr.train_step(pipe(_batch(s)), s).item() for s in range(2)]
+    assert all(np.isfinite(losses)) and abs(losses[0] - np.log(4096)) < 1.0, losses
