@@ -12,7 +12,8 @@ import torch  # noqa: F401  -- MUST precede the CDLL below: both link libamdhip6
 #                              one already mapped, otherwise the process ends up with two HIP runtimes (hipErrorNoDevice)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libchadavit_hip.so")
+# CHADAVIT_HIP_LIB: load another build of the same ABI instead (same-box A/B of kernel variants; see scratch/)
+LIB_PATH = os.environ.get("CHADAVIT_HIP_LIB") or os.path.join(HERE, "libchadavit_hip.so")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "chadavit_hip.h")
 ABI_VERSION = 2
 

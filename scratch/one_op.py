@@ -36,8 +36,17 @@ elif name == "proj_ffn":  # the whole-block kernel, training instance (H, z, y s
     slab = torch.cat([slab, wq.reshape(-1)])
     ops.ffn_pack_proj_batched(slab, pkp, torch.tensor([0, w1.numel(), w1.numel() + w2.numel(), w1.numel() + w2.numel() + wo.numel(), 0], device=dev), 1, D, FF)
     bq = torch.zeros(3 * D, device=dev); qkv = torch.empty((T, 3 * D), device=dev, dtype=bf)
+    rb_ = ops.relu_bits_buffer(T, FF, dev)   # round 2: the training instance also records the ReLU bit pattern
     fn = lambda: ops.proj_ffn_ln_fwd(a, xr, pkp, z0, ln, f0, z0, ln, y=y, x1=x1, stats1=st, z=z, h=h, ln_b=ln, stats_a=st, stats_b=st,
-                                     qkv_bias=bq, qkv=qkv)
+                                     qkv_bias=bq, qkv=qkv, relu_bits=rb_)
+elif name == "ffn_bwd_dx":  # dx1 = dz + ((dz W2) * [H > 0]) W1 in one launch, dpre written for the dW1 GEMM
+    D, FF = 192, 2048
+    dz = torch.randn((T, D), device=dev).to(bf)
+    w1t = (torch.randn((D, FF), device=dev) / D ** .5).to(bf); w2t = (torch.randn((FF, D), device=dev) / FF ** .5).to(bf)
+    pkb = ops.ffn_pack(w2t, w1t)
+    rb_ = torch.randint(0, 256, (int(ops.relu_bits_buffer(T, FF, dev).numel()),), device=dev, dtype=torch.uint8)
+    dx = torch.empty((T, D), device=dev, dtype=bf); dp = torch.empty((T, FF), device=dev, dtype=bf)
+    fn = lambda: ops.ffn_bwd_dx(dz, pkb, rb_, dx1=dx, dpre=dp)
 elif name in ("attn_fwd", "attn_bwd"):
     rb = RaggedBatch([3] * (T // 589), 196, dev)
     qkv = torch.randn((rb.T, 576), device=dev).to(bf)
