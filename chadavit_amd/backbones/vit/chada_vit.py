@@ -258,13 +258,17 @@ def _tokenize(m: ChAdaViT, flat: FlatParams, x, rb: RaggedBatch, pos_patch, add_
     S = x.shape[-1]
     ps = m.token_learner.patch_size
     D = m.embed_dim
-    patches = ops.im2col(x.reshape(-1, S, S).float().contiguous(), ps)
+    xs = x.reshape(-1, S, S).float().contiguous()
     tokens = torch.empty((rb.T, D), device=x.device, dtype=torch.bfloat16)
     chan = flat.f("channel_token").view(m.max_channels, D) if add_chan else None
-    ops.tokenizer_gemm(patches, flat.w("token_learner.proj.weight"), flat.f("token_learner.proj.bias"), pos_patch, chan,
-                       rb.chan_img, rb.chan_idx, tokens, rb.p)
+    if ps == 16:  # the conv unfold happens inside the GEMM's operand staging: no patch buffer in HBM
+        ops.tokenizer_fused(xs, flat.w("token_learner.proj.weight"), flat.f("token_learner.proj.bias"), pos_patch, chan, rb.chan_img,
+                            rb.chan_idx, tokens, rb.p)
+    else:
+        ops.tokenizer_gemm(ops.im2col(xs, ps), flat.w("token_learner.proj.weight"), flat.f("token_learner.proj.bias"), pos_patch, chan,
+                           rb.chan_img, rb.chan_idx, tokens, rb.p)
     ops.write_cls(tokens, rb.cu_seqlens, flat.f("cls_token").view(-1), flat.f("pos_embed").view(-1, D)[0].contiguous())
-    return tokens, patches
+    return tokens, xs
 
 
 def _linear(m: ChAdaViT, flat: FlatParams, xb, wname: str, bias, epilogue=ops.EPI_NONE, aux=None):
@@ -486,8 +490,11 @@ class _BackboneFn(torch.autograd.Function):
         # tokenizer backward (autograd of chada_vit.py:223-265)
         dpatch, dpos, dchan, dcls = ops.tokenizer_bwd(dx, rb.cu_seqlens, rb.chan_img, rb.chan_idx, rb.p, m.max_channels)
         gw = G("token_learner.proj.weight")
-        ops.gemm_tn(dpatch, ctx.patches, gw.view(D, -1), colsum=G("token_learner.proj.bias"), accumulate=acc, workspace=tn_ws,
+        # the unfolded patches exist only here, for the weight gradient of the patch conv (the forward gathers them on the fly)
+        patches = ops.im2col(ctx.patches, m.token_learner.patch_size)
+        ops.gemm_tn(dpatch, patches, gw.view(D, -1), colsum=G("token_learner.proj.bias"), accumulate=acc, workspace=tn_ws,
                     t_rows=rb.n_chan * rb.p)
+        del patches
         gcls, gchan, gpos = G("cls_token").view(-1), G("channel_token").view(m.max_channels, D), G("pos_embed").view(-1, D)
         if not acc:
             gchan.zero_()

@@ -33,7 +33,18 @@ struct NtArgs {
   const int* chan_img;
   const int* chan_idx;
   int p;
+  // tokenizer with the patch gather folded into the X staging (no im2col buffer): X row m = patch (m % p) of channel image m / p
+  // of img [n_chan, S, S] fp32, k = u * 16 + v inside the 16 x 16 patch
+  const float* img;
+  int S;
 };
+
+__device__ __forceinline__ bf16x8 pack8f(const f32x4& a, const f32x4& b) {
+  bf16x8 r;
+  r[0] = (bf16_t)a[0]; r[1] = (bf16_t)a[1]; r[2] = (bf16_t)a[2]; r[3] = (bf16_t)a[3];
+  r[4] = (bf16_t)b[0]; r[5] = (bf16_t)b[1]; r[6] = (bf16_t)b[2]; r[7] = (bf16_t)b[3];
+  return r;
+}
 
 // XCD-aware bijective remap: hardware places block b on XCD b % 8; give each XCD a contiguous run of
 // logical tiles so the N-tiles that share one X row-panel hit the same L2.
@@ -135,8 +146,34 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NtArgs a) {
   for (int i = 0; i < XCH; ++i) xsrc[i] = gX + (size_t)min(m0 + srow + 32 * i, M - 1) * ldx + sch * 8;
   const bf16_t* wsrc = gW + (size_t)(n0 + srow) * ldw + sch * 8;
   u32x4 xr[XCH], wr[WCH];
+  // EPI_TOKEN with a.img: the X tile is gathered straight from the fp32 image (conv unfold of chada_vit.py:128-133 folded into
+  // the GEMM's staging): chunk (row, sch) of k-tile k0 = 8 consecutive pixels of patch row u = (k0 + 8 sch) / 16
+  const float* isrc[XCH];
+  const float* const gimg = (EPI == EPI_TOKEN) ? a.img : nullptr;
+  if constexpr (EPI == EPI_TOKEN) {
+    if (gimg != nullptr) {
+      const int S = a.S, gq = S >> 4;
+#pragma unroll
+      for (int i = 0; i < XCH; ++i) {
+        const int m = min(m0 + srow + 32 * i, M - 1);
+        const int ci = m / a.p, pi = m - ci * a.p;
+        const int r = pi / gq, q = pi - r * gq;
+        isrc[i] = gimg + ((size_t)ci * S + 16 * r + (sch >> 1)) * S + 16 * q + (sch & 1) * 8;
+      }
+    }
+  }
+  const int img_k_stride = (EPI == EPI_TOKEN && gimg != nullptr) ? (a.S * (BK / 16)) : 0;  // floats per k-tile: 4 patch rows
 #define LOAD_REGS(k0)                                                                        \
   {                                                                                          \
+    if (EPI == EPI_TOKEN && gimg != nullptr) {                                               \
+      _Pragma("unroll") for (int i = 0; i < XCH; ++i) {                                      \
+        const float* ps_ = isrc[i] + (size_t)((k0) / BK) * img_k_stride;                     \
+        const f32x4 a0_ = *reinterpret_cast<const f32x4*>(ps_);                              \
+        const f32x4 a1_ = *reinterpret_cast<const f32x4*>(ps_ + 4);                          \
+        const bf16x8 o_ = pack8f(a0_, a1_);                                                  \
+        xr[i] = __builtin_bit_cast(u32x4, o_);                                               \
+      }                                                                                      \
+    } else                                                                                   \
     _Pragma("unroll") for (int i = 0; i < XCH; ++i) xr[i] = *reinterpret_cast<const u32x4*>(xsrc[i] + (k0)); \
     _Pragma("unroll") for (int i = 0; i < WCH; ++i)                                          \
         wr[i] = *reinterpret_cast<const u32x4*>(wsrc + (size_t)(32 * i) * ldw + (k0));       \
@@ -591,5 +628,23 @@ extern "C" int chadavit_tokenizer_gemm(const chada_bf16* patches, const chada_bf
   a.bias = bias;
   a.M = Mp; a.N = D; a.K = K; a.ldx = K; a.ldw = K; a.ldo = D;
   a.pos = pos; a.chan = chan; a.chan_img = chan_img; a.chan_idx = chan_idx; a.p = p;
+  return launch_nt<EPI_TOKEN, false>(a, reinterpret_cast<hipStream_t>(stream));
+}
+
+// The same with the conv unfold folded into the GEMM (no im2col buffer): x [n_chan, S, S] fp32, 16 x 16 patches (K = 256).
+extern "C" int chadavit_tokenizer_fused(const float* x, const chada_bf16* Wp, const float* bias, const float* pos, const float* chan,
+                                        const int* chan_img, const int* chan_idx, chada_bf16* tokens, int n_chan, int S, int D, int p,
+                                        void* stream) {
+  CHADA_ENTRY();
+  if (!x || !Wp || !pos || !chan_img || !chan_idx || !tokens || n_chan <= 0 || S <= 0 || p <= 0) return 1;
+  if (S % 16 != 0 || p != (S / 16) * (S / 16) || D % 64 != 0 || ((uintptr_t)x & 15) != 0) return 2;
+  NtArgs a{};
+  a.X = reinterpret_cast<const bf16_t*>(x);  // unused: the staging reads a.img
+  a.W = reinterpret_cast<const bf16_t*>(Wp);
+  a.Out = tokens;
+  a.bias = bias;
+  a.M = n_chan * p; a.N = D; a.K = 256; a.ldx = 256; a.ldw = 256; a.ldo = D;
+  a.pos = pos; a.chan = chan; a.chan_img = chan_img; a.chan_idx = chan_idx; a.p = p;
+  a.img = x; a.S = S;
   return launch_nt<EPI_TOKEN, false>(a, reinterpret_cast<hipStream_t>(stream));
 }

@@ -81,48 +81,62 @@ __global__ __launch_bounds__(256) void tokbwd_compact_kernel(const bf16_t* __res
     *reinterpret_cast<u32x4*>(dpatch + (size_t)m * D + c) = *reinterpret_cast<const u32x4*>(dtok + (size_t)row * D + c);
   }
 }
-// (2) dpos[j, :] = sum over channel instances of dpatch[gc*p + j, :]   (block = patch position j)
-__global__ __launch_bounds__(256) void tokbwd_dpos_kernel(const bf16_t* __restrict__ dpatch, float* __restrict__ dpos,
-                                                          int n_chan, int p, int D) {
-  // block = (patch position j, 64-column slice); the 4 waves split the channel instances, lanes own columns
-  __shared__ float red[4][64];
-  const int j = blockIdx.x, d = blockIdx.y * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
-  float s = 0.f;
-  if (d < D)
-    for (int gc = w; gc < n_chan; gc += 4) s += (float)dpatch[((size_t)gc * p + j) * D + d];
-  red[w][threadIdx.x & 63] = s;
-  __syncthreads();
-  if (w == 0 && d < D) dpos[(size_t)j * D + d] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-}
-// (3) per channel-slot sums: dchan[c, :] = sum_{gc: chan_idx[gc]==c} sum_j dpatch[gc*p+j, :]
-//     grid = (max_channels, SPL); each block sums a strided share of the channel instances -> partial slabs
-__global__ __launch_bounds__(256) void tokbwd_dchan_part_kernel(const bf16_t* __restrict__ dpatch,
-                                                                const int* __restrict__ chan_idx, float* __restrict__ part,
-                                                                int n_chan, int p, int D, int max_c) {
-  const int c = blockIdx.x, sp = blockIdx.y, nsp = gridDim.y;
-  for (int d = threadIdx.x; d < D; d += blockDim.x) {
-    float s = 0.f;
-    for (int gc = sp; gc < n_chan; gc += nsp) {
-      if (chan_idx[gc] != c) continue;
-      const bf16_t* base = dpatch + (size_t)gc * p * D + d;
-      for (int j = 0; j < p; ++j) s += (float)base[(size_t)j * D];
+// (2) ONE pass over the patch-token rows of dtok: slot[c][j][:] = sum over the channel instances gc with chan_idx[gc] == c of
+//     dtok[row(gc, j)][:], row(gc, j) = gc * p + j + chan_img[gc] + 1.  Block = (patch position j, channel slot c); the 4 waves
+//     split the instances, a lane owns 4 consecutive columns (8-byte loads), partials meet in LDS.  Everything the tokenizer's
+//     three parameter gradients need is a marginal of this [max_c, p, D] table (1.5 MB at Tiny):
+//       dpos[j] = sum_c slot[c][j]      dchan[c] = sum_j slot[c][j]
+//     (round 1 made four passes with 192-thread serial loops: 0.55 ms per step at cfg2).
+__global__ __launch_bounds__(256) void tokbwd_slot_kernel(const bf16_t* __restrict__ dtok, const int* __restrict__ chan_img,
+                                                          const int* __restrict__ chan_idx, float* __restrict__ slot, int n_chan,
+                                                          int p, int D) {
+  __shared__ f32x4 red[4][64];
+  const int j = blockIdx.x, c = blockIdx.y, l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int d0 = 0; d0 < D; d0 += 256) {
+    const int d = d0 + 4 * l;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (d < D) {
+      for (int gc = w; gc < n_chan; gc += 4) {
+        if (chan_idx[gc] != c) continue;  // wave-uniform
+        const bf16x4 v = *reinterpret_cast<const bf16x4*>(dtok + ((size_t)gc * p + j + chan_img[gc] + 1) * D + d);
+        s[0] += (float)v[0]; s[1] += (float)v[1]; s[2] += (float)v[2]; s[3] += (float)v[3];
+      }
     }
-    part[((size_t)sp * max_c + c) * D + d] = s;
+    red[w][l] = s;
+    __syncthreads();
+    if (w == 0 && d < D)
+      *reinterpret_cast<f32x4*>(slot + ((size_t)c * p + j) * D + d) = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+    __syncthreads();
   }
 }
-__global__ __launch_bounds__(256) void tokbwd_finish_kernel(const float* __restrict__ part, const bf16_t* __restrict__ dtok,
-                                                            const int* __restrict__ cu, float* __restrict__ dchan,
-                                                            float* __restrict__ dcls, int nsp, int max_c, int B, int D) {
-  const int id = blockIdx.x * blockDim.x + threadIdx.x;
-  if (id < max_c * D) {
+// (3) the marginals + dcls.  Blocks [0, p): dpos rows; [p, p + max_c): dchan rows; block p + max_c: dcls = sum_i dtok[cu[i]].
+__global__ __launch_bounds__(256) void tokbwd_finish_kernel(const float* __restrict__ slot, const bf16_t* __restrict__ dtok,
+                                                            const int* __restrict__ cu, float* __restrict__ dpos,
+                                                            float* __restrict__ dchan, float* __restrict__ dcls, int p, int max_c,
+                                                            int B, int D) {
+  __shared__ float red[4][64];
+  const int b = blockIdx.x, l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int d0 = 0; d0 < D; d0 += 64) {
+    const int d = d0 + l;
     float s = 0.f;
-    for (int sp = 0; sp < nsp; ++sp) s += part[(size_t)sp * max_c * D + id];
-    dchan[id] = s;
-  } else if (id < (max_c + 1) * D) {
-    const int d = id - max_c * D;
-    float s = 0.f;
-    for (int i = 0; i < B; ++i) s += (float)dtok[(size_t)cu[i] * D + d];
-    dcls[d] = s;
+    if (d < D) {
+      if (b < p) {
+        for (int c = w; c < max_c; c += 4) s += slot[((size_t)c * p + b) * D + d];
+      } else if (b < p + max_c) {
+        for (int j = w; j < p; j += 4) s += slot[((size_t)(b - p) * p + j) * D + d];
+      } else {
+        for (int i = w; i < B; i += 4) s += (float)dtok[(size_t)cu[i] * D + d];
+      }
+    }
+    red[w][l] = s;
+    __syncthreads();
+    if (w == 0 && d < D) {
+      const float t = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+      if (b < p) dpos[(size_t)b * D + d] = t;
+      else if (b < p + max_c) dchan[(size_t)(b - p) * D + d] = t;
+      else dcls[d] = t;
+    }
+    __syncthreads();
   }
 }
 
@@ -185,24 +199,24 @@ extern "C" int chadavit_tokenizer_bwd(const chada_bf16* dtok_, const int* cu_seq
                                       int B, int n_chan, int p, int D, int max_channels, void* stream) {
   CHADA_ENTRY();
   if (!dtok_ || !cu_seqlens || !chan_img || !chan_idx || !dpatch_tok || !dpos || !dchan || !dcls || !workspace) return 1;
-  if (B <= 0 || n_chan <= 0 || p <= 0 || D % 8 != 0 || max_channels <= 0) return 2;
+  if (B <= 0 || n_chan <= 0 || p <= 0 || D % 8 != 0 || max_channels <= 0 || ((uintptr_t)workspace & 15) != 0) return 2;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const bf16_t* dtok = reinterpret_cast<const bf16_t*>(dtok_);
   bf16_t* dpatch = reinterpret_cast<bf16_t*>(dpatch_tok);
   const int Mp = n_chan * p;
   hipLaunchKernelGGL(tokbwd_compact_kernel, dim3(grid_for((size_t)Mp * D / 8, 8192)), dim3(256), 0, s, dtok, chan_img, dpatch,
                      Mp, p, D);
-  hipLaunchKernelGGL(tokbwd_dpos_kernel, dim3(p, (D + 63) / 64), dim3(256), 0, s, dpatch, dpos, n_chan, p, D);
-  const int nsp = chadavit_tokenizer_bwd_splits();
-  hipLaunchKernelGGL(tokbwd_dchan_part_kernel, dim3(max_channels, nsp), dim3(256), 0, s, dpatch, chan_idx, workspace, n_chan, p,
-                     D, max_channels);
-  hipLaunchKernelGGL(tokbwd_finish_kernel, dim3(((max_channels + 1) * D + 255) / 256), dim3(256), 0, s, workspace, dtok,
-                     cu_seqlens, dchan, dcls, nsp, max_channels, B, D);
+  hipLaunchKernelGGL(tokbwd_slot_kernel, dim3(p, max_channels), dim3(256), 0, s, dtok, chan_img, chan_idx, workspace, n_chan, p, D);
+  hipLaunchKernelGGL(tokbwd_finish_kernel, dim3(p + max_channels + 1), dim3(256), 0, s, workspace, dtok, cu_seqlens, dpos, dchan, dcls,
+                     p, max_channels, B, D);
   CHADA_CHECK_LAUNCH();
   return 0;
 }
 
-extern "C" int chadavit_tokenizer_bwd_splits(void) { return 128; }
+extern "C" long long chadavit_tokenizer_bwd_workspace_floats(int p, int D, int max_channels) {
+  if (p <= 0 || D <= 0 || max_channels <= 0) return -1;
+  return (long long)max_channels * p * D;
+}
 
 
 // ---- per-channel intensity jitter on the collated crop tensor (the tokenizer's input), in place.

@@ -332,6 +332,22 @@ def tokenizer_gemm(patches, wp, bias, pos, chan, chan_img, chan_idx, tokens, p):
     return tokens
 
 
+def tokenizer_fused(x, wp, bias, pos, chan, chan_img, chan_idx, tokens, p):
+    """Patch embed straight from the fp32 crops x (n_chan, S, S): conv unfold folded into the GEMM's operand staging."""
+    _req(x, F32, "x"); _req(wp, BF16, "wp"); _req(bias, F32, "bias"); _req(pos, F32, "pos")
+    _req(chan_img, I32, "chan_img"); _req(chan_idx, I32, "chan_idx"); _req(tokens, BF16, "tokens")
+    if chan is not None:
+        _req(chan, F32, "chan")
+    n_chan, S = x.shape[0], x.shape[-1]
+    D = wp.shape[0]
+    if wp.shape[1] != 256:
+        raise RuntimeError("tokenizer_fused: 16 x 16 patches only")
+    rc = lib().chadavit_tokenizer_fused(_ptr(x), _ptr(wp), _ptr(bias), _ptr(pos), _ptr(chan), _ptr(chan_img), _ptr(chan_idx), _ptr(tokens),
+                                        c_int(n_chan), c_int(S), c_int(D), c_int(p), _stream())
+    _chk(rc, "chadavit_tokenizer_fused")
+    return tokens
+
+
 def write_cls(tokens, cu, cls, pos0):
     _req(tokens, BF16, "tokens"); _req(cu, I32, "cu"); _req(cls, F32, "cls"); _req(pos0, F32, "pos0")
     B, D = cu.numel() - 1, tokens.shape[1]
@@ -481,7 +497,7 @@ def tokenizer_bwd(dtok, cu, chan_img, chan_idx, p, max_channels):
     dpos = torch.empty((p, D), device=dev, dtype=F32)
     dchan = torch.empty((max_channels, D), device=dev, dtype=F32)
     dcls = torch.empty((D,), device=dev, dtype=F32)
-    ws = torch.empty(lib().chadavit_tokenizer_bwd_splits() * max_channels * D, device=dev, dtype=F32)
+    ws = torch.empty(int(lib().chadavit_tokenizer_bwd_workspace_floats(c_int(p), c_int(D), c_int(max_channels))), device=dev, dtype=F32)
     rc = lib().chadavit_tokenizer_bwd(_ptr(dtok), _ptr(cu), _ptr(chan_img), _ptr(chan_idx), _ptr(dpatch), _ptr(dpos), _ptr(dchan),
                                       _ptr(dcls), _ptr(ws), c_int(B), c_int(n_chan), c_int(p), c_int(D), c_int(max_channels), _stream())
     _chk(rc, "chadavit_tokenizer_bwd")

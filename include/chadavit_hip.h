@@ -55,6 +55,12 @@ int chadavit_tokenizer_gemm(const chada_bf16* patches, const chada_bf16* Wp, con
 /* im2col for the 1->D, k=stride=patch conv: x fp32 [n_chan, S, S] -> patches bf16 [n_chan*(S/patch)^2, patch*patch]
  * (row = chan*p + r*g + q, col = u*patch + v).  replaces the unfold inside Conv2d (chada_vit.py:128). */
 int chadavit_im2col(const float* x, chada_bf16* patches, int n_chan, int S, int patch, void* stream);
+/* tokenizer GEMM with the conv unfold folded into its operand staging (no patch buffer in HBM): x [n_chan, S, S] fp32 (16-byte
+ * aligned), 16 x 16 patches, p = (S/16)^2; same epilogue / outputs as chadavit_tokenizer_gemm.  Replaces chada_vit.py:128-133 +
+ * :226-268 in one launch (+ chadavit_write_cls). */
+int chadavit_tokenizer_fused(const float* x, const chada_bf16* Wp, const float* bias, const float* pos, const float* chan,
+                             const int* chan_img, const int* chan_idx, chada_bf16* tokens, int n_chan, int S, int D, int p,
+                             void* stream);
 
 /* CLS rows: tokens[cu_seqlens[i], :] = cls + pos0        (chada_vit.py:256-265) */
 int chadavit_write_cls(chada_bf16* tokens, const int* cu_seqlens, const float* cls, const float* pos0, int B, int D,
@@ -135,7 +141,7 @@ int chadavit_scatter_rows_zero(const chada_bf16* src, const int* rows, chada_bf1
 int chadavit_tokenizer_bwd(const chada_bf16* dtok, const int* cu_seqlens, const int* chan_img, const int* chan_idx,
                            chada_bf16* dpatch_tok, float* dpos, float* dchan, float* dcls, float* workspace, int B,
                            int n_chan, int p, int D, int max_channels, void* stream);
-int chadavit_tokenizer_bwd_splits(void); /* workspace >= splits * max_channels * D floats */
+long long chadavit_tokenizer_bwd_workspace_floats(int p, int D, int max_channels); /* workspace size in floats (16-byte aligned) */
 
 /* ---------------------------------------------------------------------------------------------
  * DINO head pieces (dino.py:98-111): row L2 normalise (F.normalize eps 1e-12) and weight-norm of the

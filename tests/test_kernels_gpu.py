@@ -325,6 +325,11 @@ def test_tokenizer_path():
     _close(patches, ref_patches.bfloat16(), 0, 0, "im2col")
     tokens = torch.zeros((rb.T, D), device=dev, dtype=torch.bfloat16)
     ops.tokenizer_gemm(patches, W.view(D, -1).bfloat16().contiguous(), bias, pos, chan, rb.chan_img, rb.chan_idx, tokens, p)
+    # the same GEMM with the unfold folded into its operand staging (no patch buffer): bit-identical tokens
+    tokens_f = torch.zeros((rb.T, D), device=dev, dtype=torch.bfloat16)
+    ops.tokenizer_fused(x.view(-1, S, S).contiguous(), W.view(D, -1).bfloat16().contiguous(), bias, pos, chan, rb.chan_img, rb.chan_idx,
+                        tokens_f, p)
+    assert torch.equal(tokens_f, tokens)
     ops.write_cls(tokens, rb.cu_seqlens, cls, pos0)
     conv = torch.nn.functional.conv2d(x.bfloat16().float(), W.bfloat16().float(), bias, stride=P).flatten(2).transpose(1, 2)
     rows, off = [], 0
