@@ -300,8 +300,8 @@ def replay_launches(counts, nch, wl, dev, reps=10):
             _, M, N, K, epi = key
             xq = torch.randint(0, 120, (M, K), device=dev, dtype=torch.uint8)
             wq = torch.randint(0, 120, (N, K), device=dev, dtype=torch.uint8)
-            xs_ = torch.full((K // 32, M), 120, device=dev, dtype=torch.uint8)
-            ws_ = torch.full((K // 32, N), 120, device=dev, dtype=torch.uint8)
+            xs_ = torch.full((K // 32, (M + 3) // 4 * 4), 120, device=dev, dtype=torch.uint8)[:, :M]
+            ws_ = torch.full((K // 32, (N + 3) // 4 * 4), 120, device=dev, dtype=torch.uint8)[:, :N]
             bias = torch.zeros(N, device=dev)
             aux = torch.randn((M, N), device=dev).to(bf) if epi == 3 else None
             o = torch.empty((M, N), device=dev, dtype=bf)

@@ -15,10 +15,11 @@
 // 2 + (g >> 1)).  The scale operand (byte 0 with opsel 0) of lane group s is the E8M0 scale of 32-k block s of that row / column.
 // C/D is the usual 16x16 map (row = (l >> 4) * 4 + i, col = l & 15).
 //
-// Kernel: 128 x 128 x 128 tile, 4 waves (2 x 2, 64 x 64 each = 4 x 4 MFMA tiles), two LDS stages filled by LDS-DMA
-// (buffer_load ... lds, 16 bytes per lane); rows are 128 bytes, the 16-byte slots of a row are XOR-swizzled with (row >> 1) & 7
-// on the DMA source side and on the fragment reads (a ds_read_b128 lane group then covers 16 distinct slots).  The MFMA is
-// issued as D[n][m] (A = W fragment, B = X fragment) so a lane ends up with four consecutive n of one output row: 8-byte stores.
+// Kernel: 256 x 128 x 128 tile, 8 waves (4 x 2, 64 x 64 each = 4 x 4 MFMA tiles), three LDS stages filled by LDS-DMA two k-tiles
+// ahead (buffer_load ... lds, 16 bytes per lane; the scale bytes of the tile ride the same ring as 4-byte pieces); rows are 128
+// bytes, the 16-byte slots of a row are XOR-swizzled with (row >> 1) & 7 on the DMA source side and on the fragment reads (a
+// ds_read_b128 lane group then covers 16 distinct slots).  The MFMA is issued as D[n][m] (A = W fragment, B = X fragment) so a
+// lane ends up with four consecutive n of one output row: 8-byte stores.
 #include "common.h"
 
 namespace {
@@ -26,16 +27,21 @@ using namespace chada;
 
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 
-constexpr int MX_BM = 128, MX_BN = 128, MX_BK = 128;  // BK bytes = fp8 elements
-constexpr int MX_TILE = MX_BM * MX_BK;                // bytes of one operand tile in LDS (16 KiB)
+constexpr int MX_BM = 256, MX_BN = 128, MX_BK = 128;  // BK bytes = fp8 elements
+constexpr int MX_XT = MX_BM * MX_BK;                   // X tile bytes in LDS (32 KiB)
+constexpr int MX_WT = MX_BN * MX_BK;                   // W tile bytes (16 KiB)
+constexpr int MX_XS = MX_XT + MX_WT;                   // X scales [4][256] (1 KiB) ...
+constexpr int MX_WS = MX_XS + 4 * MX_BM;               // ... W scales [4][128] (512 B, slot padded to 1 KiB)
+constexpr int MX_STAGE = MX_WS + 1024;                 // 50 KiB per stage; three stages = 150 KiB: one 8-wave block per CU
+constexpr int MX_NSTG = 3;
 
-enum { MXE_NONE = 0, MXE_RELU = 1, MXE_RESID = 3 };   // numbering as the bf16 GEMM's epilogues
+enum { MXE_NONE = 0, MXE_RELU = 1, MXE_RESID = 3 };    // numbering as the bf16 GEMM's epilogues
 
 struct Mx8Args {
-  const uint8_t* Xq; const uint8_t* xs;   // [M, K] fp8, [K/32, M] e8m0
-  const uint8_t* Wq; const uint8_t* ws;   // [N, K] fp8, [K/32, N] e8m0
+  const uint8_t* Xq; const uint8_t* xs;   // [M, K] fp8, [K/32, lds_x] e8m0 (row stride lds_x >= M, multiple of 4)
+  const uint8_t* Wq; const uint8_t* ws;   // [N, K] fp8, [K/32, lds_w] e8m0
   bf16_t* Out; const float* bias; const bf16_t* aux;
-  int M, N, K, ldo, ldaux;
+  int M, N, K, ldo, ldaux, lds_x, lds_w;
 };
 
 __device__ __forceinline__ int mx_xcd_remap(int bid, int nblk) {
@@ -44,29 +50,40 @@ __device__ __forceinline__ int mx_xcd_remap(int bid, int nblk) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-// one pipeline step: DMA of the next k-tile (when `issue`), fragment reads + 16 MFMAs of the current one.  The LDS pointers are
-// __restrict__ parameters on purpose: the reads then carry noalias scopes against the DMA and hipcc does not drain it.
-__device__ __forceinline__ void mx8_step(BufRsrc xr, BufRsrc wr, uint8_t* __restrict__ dst, const uint8_t* __restrict__ st, bool issue,
-                                         const unsigned (&xoff)[4], const unsigned (&woff)[4], unsigned kbyte, int l,
-                                         const unsigned (&a_addr)[4][2], const unsigned (&b_addr)[4][2],
-                                         const int (&sa)[4], const int (&sb)[4], f32x4 (&acc)[4][4]) {
-  if (issue) {
+// DMA of one k-tile into the stage `dst` (bytes): per wave 4 X records + 2 W records of 1 KiB (8 rows x 128 B each), and the
+// tile's scales as 4-byte pieces (waves 0-3: one 32-k block of the 256 X rows each; waves 4, 5: two blocks of the 128 W rows each).
+__device__ __forceinline__ void mx8_issue(BufRsrc xr, BufRsrc wr, BufRsrc xsr, BufRsrc wsr, uint8_t* __restrict__ dst,
+                                          const unsigned (&xoff)[4], const unsigned (&woff)[2], unsigned kbyte, unsigned xs_off,
+                                          unsigned ws_off, int w, int l) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      lds_dma16(xr, reinterpret_cast<bf16_t*>(dst + i * 4096), xoff[i], kbyte);                // rows 32 i .. of the X tile (per wave: 4 x 8 rows)
-      lds_dma16(wr, reinterpret_cast<bf16_t*>(dst + MX_TILE + i * 4096), woff[i], kbyte);
-    }
-  }
+  for (int i = 0; i < 4; ++i) lds_dma16(xr, reinterpret_cast<bf16_t*>(dst + i * 8192 + w * 1024), xoff[i], kbyte);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) lds_dma16(wr, reinterpret_cast<bf16_t*>(dst + MX_XT + i * 8192 + w * 1024), woff[i], kbyte);
+  if (w < 4) lds_dma4(xsr, dst + MX_XS + w * 256, xs_off, 0);
+  else if (w < 6) lds_dma4(wsr, dst + MX_WS + (w - 4) * 256, ws_off, 0);
+}
+
+// one pipeline step: DMA of k-tile kt + 2 (when `issue`), fragment / scale reads + 16 MFMAs of the current one.  The LDS pointers
+// are __restrict__ parameters on purpose: the reads then carry noalias scopes against the DMA and hipcc does not drain it.
+__device__ __forceinline__ void mx8_step(BufRsrc xr, BufRsrc wr, BufRsrc xsr, BufRsrc wsr, uint8_t* __restrict__ dst,
+                                         const uint8_t* __restrict__ st, bool issue, const unsigned (&xoff)[4],
+                                         const unsigned (&woff)[2], unsigned kbyte, unsigned xs_off, unsigned ws_off, int w, int l,
+                                         const unsigned (&a_addr)[4][2], const unsigned (&b_addr)[4][2], unsigned sa_addr,
+                                         unsigned sb_addr, f32x4 (&acc)[4][4]) {
+  if (issue) mx8_issue(xr, wr, xsr, wsr, dst, xoff, woff, kbyte, xs_off, ws_off, w, l);
   __builtin_amdgcn_sched_barrier(0);
   i32x8 af[4], bfr[4];
+  int sa[4], sb[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    const u32x4 a0 = *reinterpret_cast<const u32x4*>(st + MX_TILE + a_addr[t][0]);
-    const u32x4 a1 = *reinterpret_cast<const u32x4*>(st + MX_TILE + a_addr[t][1]);
+    const u32x4 a0 = *reinterpret_cast<const u32x4*>(st + MX_XT + a_addr[t][0]);
+    const u32x4 a1 = *reinterpret_cast<const u32x4*>(st + MX_XT + a_addr[t][1]);
     const u32x4 b0 = *reinterpret_cast<const u32x4*>(st + b_addr[t][0]);
     const u32x4 b1 = *reinterpret_cast<const u32x4*>(st + b_addr[t][1]);
     af[t] = i32x8{(int)a0[0], (int)a0[1], (int)a0[2], (int)a0[3], (int)a1[0], (int)a1[1], (int)a1[2], (int)a1[3]};
     bfr[t] = i32x8{(int)b0[0], (int)b0[1], (int)b0[2], (int)b0[3], (int)b1[0], (int)b1[1], (int)b1[2], (int)b1[3]};
+    sa[t] = st[MX_WS + sa_addr + t * 16];   // W scale of (n row of tile t, k-block g)
+    sb[t] = st[MX_XS + sb_addr + t * 16];   // X scale of (m row of tile t, k-block g)
   }
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt)
@@ -75,29 +92,26 @@ __device__ __forceinline__ void mx8_step(BufRsrc xr, BufRsrc wr, uint8_t* __rest
       acc[nt][mt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af[nt], bfr[mt], acc[nt][mt], 0, 0, 0, sa[nt], 0, sb[mt]);
 }
 
+// 256 x 128 x 128 tile, 8 waves (4 x 2, 64 x 64 each), THREE LDS stages with the k-tile fetched two ahead and a counted wait, and
+// PERSISTENT blocks (one per CU, 150 KiB of LDS) that walk the output tiles: with K = 768 there are only 6 k-tiles per output tile
+// and 16 MFMAs per wave and tile (~0.26 us of matrix work) against a DMA round trip of ~2 us.  History at 125504 x 2304 x 768:
+// 128 x 128 / two stages / one tile in flight per block 509 us (872 TFLOP/s: the round-trip rate); this tile + ring, one output tile
+// per block 486 us; + the transposing epilogue 427 us (the tile's prologue and epilogue, ~5 of 12 us, had nothing to overlap with);
+// the k-tile stream now runs across output tiles: the first two k-tiles of the next output tile are in flight during the epilogue.
 template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_mx8_kernel(Mx8Args a) {
-  __shared__ __attribute__((aligned(16))) uint8_t smem[2 * 2 * MX_TILE];  // 2 stages x (X tile | W tile) = 64 KiB
+__global__ __launch_bounds__(512, 2) void gemm_mx8_kernel(Mx8Args a) {
+  __shared__ __attribute__((aligned(16))) uint8_t smem[MX_NSTG * MX_STAGE];
   const int tid = threadIdx.x, l = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w >> 1, wn = w & 1;
   const int M = a.M, N = a.N, K = a.K;
   const int tiles_n = N / MX_BN;
-  const int bid = mx_xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (bid / tiles_n) * MX_BM, n0 = (bid % tiles_n) * MX_BN;
+  const int n_tiles = ((M + MX_BM - 1) / MX_BM) * tiles_n;
   const int KT = K / MX_BK;
   const BufRsrc xr = make_rsrc(a.Xq), wr = make_rsrc(a.Wq);
-  // DMA sources: wave w fills rows [32 i + 8 w, +8) of both tiles with instruction i; lane l -> row + (l >> 3), LDS slot l & 7 holds
-  // the source slot (l & 7) ^ ((row >> 1) & 7)
-  unsigned xoff[4], woff[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = 32 * i + 8 * w + (l >> 3);
-    const int slot = (l & 7) ^ ((row >> 1) & 7);
-    xoff[i] = (unsigned)min(m0 + row, M - 1) * (unsigned)K + slot * 16;
-    woff[i] = (unsigned)(n0 + row) * (unsigned)K + slot * 16;
-  }
-  // (the LDS image of instruction i of wave w sits at i * 4096 + w * 1024 within a tile: rows 32 i + 8 w ..)
+  // scale arrays through BOUNDED resources: the 4-byte pieces of a ragged last row tile may reach past the array (reads as 0)
+  const BufRsrc xsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.xs), 0, (K / 32) * a.lds_x, 0x00020000);
+  const BufRsrc wsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.ws), 0, (K / 32) * a.lds_w, 0x00020000);
   const int r = l & 15, g = l >> 4;
   unsigned a_addr[4][2], b_addr[4][2];  // W (A operand) rows of this wave's n tiles, X (B operand) rows of its m tiles
 #pragma unroll
@@ -109,68 +123,124 @@ __global__ __launch_bounds__(256, 2) void gemm_mx8_kernel(Mx8Args a) {
       b_addr[t][h] = mrow * 128 + (((g + 4 * h) ^ ((mrow >> 1) & 7)) * 16);
     }
   }
+  const unsigned sa_addr = g * MX_BN + wn * 64 + r, sb_addr = g * MX_BM + wm * 64 + r;
+  // the block's output tiles: blockIdx.x, + gridDim.x, ... in the XCD-aware order (gridDim.x is a multiple of 8 or == n_tiles)
+  const int my_tiles = (n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int Q = my_tiles * KT;  // k-tiles this block streams
+  // ---- issue side: DMA sources of the output tile whose k-tiles are being fetched
+  unsigned xoff[4], woff[2], xs_off0, ws_off0;
+  auto set_issue_tile = [&](int ti) {
+    const int bid = mx_xcd_remap((int)blockIdx.x + ti * (int)gridDim.x, n_tiles);
+    const int m0 = (bid / tiles_n) * MX_BM, n0 = (bid % tiles_n) * MX_BN;
+    // X record i of wave w = rows [64 i + 8 w, +8) (LDS image i * 8192 + w * 1024), W record i = rows [64 i + 8 w, +8); lane l ->
+    // row + (l >> 3), LDS slot l & 7 holds the source slot (l & 7) ^ ((row >> 1) & 7)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = 64 * i + 8 * w + (l >> 3);
+      xoff[i] = (unsigned)min(m0 + row, M - 1) * (unsigned)K + ((l & 7) ^ ((row >> 1) & 7)) * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = 64 * i + 8 * w + (l >> 3);
+      woff[i] = (unsigned)(n0 + row) * (unsigned)K + ((l & 7) ^ ((row >> 1) & 7)) * 16;
+    }
+    // scale pieces of k-tile 0 (advance by 4 rows of the scale array per k-tile): X: wave w (< 4) = k-block w, lane = 4 rows;
+    // W: wave 4 + h = k-blocks 2h (lanes 0-31) and 2h + 1 (lanes 32-63), lane = 4 rows
+    xs_off0 = (unsigned)(w & 3) * a.lds_x + m0 + 4 * l;
+    ws_off0 = (unsigned)(2 * (w & 1) + (l >> 5)) * a.lds_w + n0 + 4 * (l & 31);
+  };
   f32x4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // scale bytes of k-tile kt for this lane: ws[(4 kt + g) * N + n], xs[(4 kt + g) * M + m]
-  const uint8_t* wsp[4];
-  const uint8_t* xsp[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    wsp[t] = a.ws + (size_t)g * N + (n0 + wn * 64 + t * 16 + r);
-    xsp[t] = a.xs + (size_t)g * M + min(m0 + wm * 64 + t * 16 + r, M - 1);
-  }
-  int sa[4], sb[4], san[4], sbn[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) { sa[t] = wsp[t][0]; sb[t] = xsp[t][0]; }
   int opq = 0;
   asm volatile("" : "+s"(opq));
   uint8_t* const smem_o = smem + opq;
-  // stage 0 <- k-tile 0 (bare: nothing reads LDS before the barrier); the DMA image of wave w: tile + i * 4096 + w * 1024
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    lds_dma16(xr, reinterpret_cast<bf16_t*>(smem + i * 4096 + w * 1024), xoff[i], 0u);
-    lds_dma16(wr, reinterpret_cast<bf16_t*>(smem + MX_TILE + i * 4096 + w * 1024), woff[i], 0u);
-  }
-  for (int kt = 0; kt < KT; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // k-tile kt has landed; the other stage is free
-    const bool more = kt + 1 < KT;
-    if (more) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        san[t] = wsp[t][(size_t)(4 * (kt + 1)) * N];
-        sbn[t] = xsp[t][(size_t)(4 * (kt + 1)) * M];
+  // stream positions 0 and 1 (bare: nothing reads LDS before the first barrier)
+  set_issue_tile(0);
+  int iq_tile = 0, iq_kt = 0;  // (output tile, k-tile) of the NEXT stream position to issue
+  auto issue_next = [&](uint8_t* dst) {
+    mx8_issue(xr, wr, xsr, wsr, dst, xoff, woff, (unsigned)iq_kt * MX_BK, xs_off0 + (unsigned)(4 * iq_kt) * a.lds_x,
+              ws_off0 + (unsigned)(4 * iq_kt) * a.lds_w, w, l);
+    if (++iq_kt == KT) { iq_kt = 0; ++iq_tile; if (iq_tile < my_tiles) set_issue_tile(iq_tile); }
+  };
+  issue_next(smem);
+  if (Q > 1) issue_next(smem + MX_STAGE);
+  int st_rd = 0, st_wr = 2, ckt = 0, ctile = 0;
+  bool stores_behind = false;  // the previous step ended with the 8 stores of a full output tile
+  for (int q = 0; q < Q; ++q) {
+    // stream position q has landed (only the DMA instructions of position q + 1 may still be in flight: 7 in waves 0-5, 6 in
+    // waves 6-7) and everybody is done reading -- or, after an epilogue, transposing through -- the stage position q + 2 goes into
+    if (q + 1 < Q) {
+      // (stores count in vmcnt too: right after a full-tile epilogue its 8 store instructions are the newest operations)
+      if (stores_behind) {
+        if (w < 6) asm volatile("s_waitcnt vmcnt(15) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      } else {
+        if (w < 6) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
       }
+    } else {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
-    mx8_step(xr, wr, smem_o + ((kt + 1) & 1) * 2 * MX_TILE + w * 1024, smem_o + (kt & 1) * 2 * MX_TILE, more, xoff, woff,
-             (unsigned)(kt + 1) * MX_BK, l, a_addr, b_addr, sa, sb, acc);
-    if (more) {
+    stores_behind = false;
+    const bool more = q + 2 < Q;
+    // (the issue state lives in registers: xoff / woff / scale offsets of the tile being fetched, advanced after the call)
+    mx8_step(xr, wr, xsr, wsr, smem_o + st_wr * MX_STAGE, smem_o + st_rd * MX_STAGE, more, xoff, woff, (unsigned)iq_kt * MX_BK,
+             xs_off0 + (unsigned)(4 * iq_kt) * a.lds_x, ws_off0 + (unsigned)(4 * iq_kt) * a.lds_w, w, l, a_addr, b_addr, sa_addr, sb_addr,
+             acc);
+    if (more) { if (++iq_kt == KT) { iq_kt = 0; ++iq_tile; if (iq_tile < my_tiles) set_issue_tile(iq_tile); } }
+    if (++ckt == KT) {
+      // ---- epilogue of output tile `ctile`, through the stage just consumed (free until stream position q + 3 is issued, which
+      // is behind the next barrier).  acc[nt][mt][i] = out[m = .. + mt*16 + r][n = .. + nt*16 + 4 g + i]: written straight out
+      // that is 8-byte pieces scattered over 16 rows per instruction; each wave transposes 16 rows at a time through its own
+      // slab (fp32, row stride 68 floats) and reads them back as 8 consecutive n per lane: 128-byte row segments.
+      const int bid = mx_xcd_remap((int)blockIdx.x + ctile * (int)gridDim.x, n_tiles);
+      const int m0 = (bid / tiles_n) * MX_BM, n0 = (bid % tiles_n) * MX_BN;
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave is done reading the stage
+      constexpr int STG = 64 + 4;
+      float* stage = reinterpret_cast<float*>(smem_o + st_rd * MX_STAGE) + w * 16 * STG;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) { sa[t] = san[t]; sb[t] = sbn[t]; }
-    }
-  }
-  // epilogue: acc[nt][mt][i] = out[m = m0 + wm*64 + mt*16 + r][n = n0 + wn*64 + nt*16 + 4 g + i]
+      for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    const int m = m0 + wm * 64 + mt * 16 + r;
-    if (m >= M) continue;
+        for (int nt = 0; nt < 4; ++nt) {
+          *reinterpret_cast<f32x4*>(stage + r * STG + nt * 16 + 4 * g) = acc[nt][mt];
+          acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      const int n = n0 + wn * 64 + nt * 16 + 4 * g;
-      f32x4 v = acc[nt][mt];
-      if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + n);
-      if constexpr (EPI == MXE_RELU) {
+        for (int cc = 0; cc < 2; ++cc) {
+          const int id = l + 64 * cc, row = id >> 3, ch = id & 7;
+          const int m = m0 + wm * 64 + mt * 16 + row;
+          const int n = n0 + wn * 64 + ch * 8;
+          f32x4 v0 = *reinterpret_cast<const f32x4*>(stage + row * STG + ch * 8);
+          f32x4 v1 = *reinterpret_cast<const f32x4*>(stage + row * STG + ch * 8 + 4);
+          if (m < M) {
+            if (a.bias) {
+              v0 += *reinterpret_cast<const f32x4*>(a.bias + n);
+              v1 += *reinterpret_cast<const f32x4*>(a.bias + n + 4);
+            }
+            if constexpr (EPI == MXE_RELU) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
-      } else if constexpr (EPI == MXE_RESID) {
-        const bf16x4 rr = *reinterpret_cast<const bf16x4*>(a.aux + (size_t)m * a.ldaux + n);
+              for (int i = 0; i < 4; ++i) { v0[i] = fmaxf(v0[i], 0.f); v1[i] = fmaxf(v1[i], 0.f); }
+            } else if constexpr (EPI == MXE_RESID) {
+              const bf16x8 rr = *reinterpret_cast<const bf16x8*>(a.aux + (size_t)m * a.ldaux + n);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] += (float)rr[i];
+              for (int i = 0; i < 4; ++i) { v0[i] += (float)rr[i]; v1[i] += (float)rr[4 + i]; }
+            }
+            bf16x8 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { o[i] = (bf16_t)v0[i]; o[4 + i] = (bf16_t)v1[i]; }
+            *reinterpret_cast<bf16x8*>(a.Out + (size_t)m * a.ldo + n) = o;
+          }
+        }
       }
-      *reinterpret_cast<bf16x4*>(a.Out + (size_t)m * a.ldo + n) = pack4(v[0], v[1], v[2], v[3]);
+      ckt = 0;
+      ++ctile;
+      stores_behind = m0 + MX_BM <= M;  // every lane stored: exactly 8 store instructions per wave
     }
+    st_rd = st_rd == MX_NSTG - 1 ? 0 : st_rd + 1;
+    st_wr = st_wr == MX_NSTG - 1 ? 0 : st_wr + 1;
   }
 }
 
@@ -178,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mx8_kernel(Mx8Args a) {
 // Scale: 2^e with e = floor(log2(amax)) - 8 (OCP MX: the largest element lands in [256, 512)), raised by one when that would
 // push the largest element above e4m3's 448 (no saturation, no NaN); an all-zero block gets scale 1.
 __global__ __launch_bounds__(256) void mx8_quantize_kernel(const bf16_t* __restrict__ x, int ldx, uint8_t* __restrict__ q,
-                                                           uint8_t* __restrict__ s, long long n_blocks, int R, int K, int relu) {
+                                                           uint8_t* __restrict__ s, int lds, long long n_blocks, int R, int K, int relu) {
   const int KB = K / 32;
   for (long long id = blockIdx.x * 256ll + threadIdx.x; id < n_blocks; id += (long long)gridDim.x * 256ll) {
     const int row = (int)(id / KB), kb = (int)(id % KB);
@@ -216,43 +286,47 @@ __global__ __launch_bounds__(256) void mx8_quantize_kernel(const bf16_t* __restr
     u32x4* dst = reinterpret_cast<u32x4*>(q + (size_t)row * K + kb * 32);
     dst[0] = u32x4{out[0], out[1], out[2], out[3]};
     dst[1] = u32x4{out[4], out[5], out[6], out[7]};
-    s[(size_t)kb * R + row] = (uint8_t)e8;
+    s[(size_t)kb * lds + row] = (uint8_t)e8;
   }
 }
 
 }  // namespace
 
-extern "C" int chadavit_mx8_quantize(const chada_bf16* x, int ldx, void* q, void* scales, int R, int K, int relu, void* stream) {
+extern "C" int chadavit_mx8_quantize(const chada_bf16* x, int ldx, void* q, void* scales, int lds, int R, int K, int relu,
+                                     void* stream) {
   CHADA_ENTRY();
   if (!x || !q || !scales || R <= 0 || K <= 0) return 1;
-  if (K % 32 != 0 || ldx % 8 != 0 || ((uintptr_t)q & 15) != 0) return 2;
+  if (K % 32 != 0 || ldx % 8 != 0 || ((uintptr_t)q & 15) != 0 || lds < R || lds % 4 != 0 || ((uintptr_t)scales & 3) != 0) return 2;
   const long long nb = (long long)R * (K / 32);
   long long grid = (nb + 255) / 256;
   if (grid > 16384) grid = 16384;
   hipLaunchKernelGGL(mx8_quantize_kernel, dim3((unsigned)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     reinterpret_cast<const bf16_t*>(x), ldx, reinterpret_cast<uint8_t*>(q), reinterpret_cast<uint8_t*>(scales), nb, R, K,
-                     relu);
+                     reinterpret_cast<const bf16_t*>(x), ldx, reinterpret_cast<uint8_t*>(q), reinterpret_cast<uint8_t*>(scales), lds, nb, R,
+                     K, relu);
   CHADA_CHECK_LAUNCH();
   return 0;
 }
 
-extern "C" int chadavit_gemm_nt_mx8(const void* Xq, const void* xs, const void* Wq, const void* ws, chada_bf16* Out, int ldo, int M, int N,
-                                    int K, const float* bias, int epilogue, const chada_bf16* aux, int ldaux, void* stream) {
+extern "C" int chadavit_gemm_nt_mx8(const void* Xq, const void* xs, int lds_x, const void* Wq, const void* ws, int lds_w, chada_bf16* Out,
+                                    int ldo, int M, int N, int K, const float* bias, int epilogue, const chada_bf16* aux, int ldaux,
+                                    void* stream) {
   CHADA_ENTRY();
   if (!Xq || !xs || !Wq || !ws || !Out || M <= 0 || N <= 0 || K <= 0) return 1;
-  if (N % MX_BN != 0 || K % MX_BK != 0 || ldo % 4 != 0 || (long long)M * K >= (1ll << 32) || (long long)N * K >= (1ll << 32)) return 2;
-  if (epilogue == MXE_RESID && (!aux || ldaux % 4 != 0)) return 1;
+  if (N % MX_BN != 0 || K % MX_BK != 0 || ldo % 8 != 0 || (long long)M * K >= (1ll << 32) || (long long)N * K >= (1ll << 32)) return 2;
+  if (lds_x < M || lds_w < N || lds_x % 4 != 0 || lds_w % 4 != 0 || (((uintptr_t)xs | (uintptr_t)ws) & 3) != 0) return 2;
+  if (epilogue == MXE_RESID && (!aux || ldaux % 8 != 0)) return 1;
   Mx8Args a;
   a.Xq = reinterpret_cast<const uint8_t*>(Xq); a.xs = reinterpret_cast<const uint8_t*>(xs);
   a.Wq = reinterpret_cast<const uint8_t*>(Wq); a.ws = reinterpret_cast<const uint8_t*>(ws);
   a.Out = reinterpret_cast<bf16_t*>(Out); a.bias = bias; a.aux = reinterpret_cast<const bf16_t*>(aux);
-  a.M = M; a.N = N; a.K = K; a.ldo = ldo; a.ldaux = ldaux;
-  const dim3 grid(((M + MX_BM - 1) / MX_BM) * (N / MX_BN));
+  a.M = M; a.N = N; a.K = K; a.ldo = ldo; a.ldaux = ldaux; a.lds_x = lds_x; a.lds_w = lds_w;
+  const int n_tiles = ((M + MX_BM - 1) / MX_BM) * (N / MX_BN);
+  const dim3 grid(n_tiles < 256 ? n_tiles : 256);  // persistent: one 8-wave block per CU (150 KiB of LDS)
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   switch (epilogue) {
-    case MXE_NONE: hipLaunchKernelGGL((gemm_mx8_kernel<MXE_NONE>), grid, dim3(256), 0, s, a); break;
-    case MXE_RELU: hipLaunchKernelGGL((gemm_mx8_kernel<MXE_RELU>), grid, dim3(256), 0, s, a); break;
-    case MXE_RESID: hipLaunchKernelGGL((gemm_mx8_kernel<MXE_RESID>), grid, dim3(256), 0, s, a); break;
+    case MXE_NONE: hipLaunchKernelGGL((gemm_mx8_kernel<MXE_NONE>), grid, dim3(512), 0, s, a); break;
+    case MXE_RELU: hipLaunchKernelGGL((gemm_mx8_kernel<MXE_RELU>), grid, dim3(512), 0, s, a); break;
+    case MXE_RESID: hipLaunchKernelGGL((gemm_mx8_kernel<MXE_RESID>), grid, dim3(512), 0, s, a); break;
     default: return 2;
   }
   CHADA_CHECK_LAUNCH();

@@ -645,7 +645,8 @@ U8 = torch.uint8
 
 
 def mx8_quantize(x, relu=False, q=None, scales=None):
-    """bf16 (R, K) -> (e4m3 bytes (R, K) uint8, E8M0 scale bytes (K/32, R) uint8): one power-of-two scale per row and 32-k block."""
+    """bf16 (R, K) -> (e4m3 bytes (R, K) uint8, E8M0 scale bytes (K/32, R) uint8 -- a view of a (K/32, ceil4(R)) buffer): one
+    power-of-two scale per row and 32-k block."""
     _req(x, BF16, "x")
     R, K = x.shape
     if K % 32 != 0:
@@ -653,22 +654,26 @@ def mx8_quantize(x, relu=False, q=None, scales=None):
     if q is None:
         q = torch.empty((R, K), device=x.device, dtype=U8)
     if scales is None:
-        scales = torch.empty((K // 32, R), device=x.device, dtype=U8)
-    _req(q, U8, "q"); _req(scales, U8, "scales")
-    _chk(lib().chadavit_mx8_quantize(_ptr(x), c_int(x.stride(0)), _ptr(q), _ptr(scales), c_int(R), c_int(K), c_int(1 if relu else 0), _stream()),
-         "chadavit_mx8_quantize")
+        scales = torch.empty((K // 32, (R + 3) // 4 * 4), device=x.device, dtype=U8)[:, :R]
+    _req(q, U8, "q")
+    if scales.dtype != U8 or scales.device != x.device or scales.stride(1) != 1 or tuple(scales.shape) != (K // 32, R):
+        raise RuntimeError("mx8_quantize: scales must be a (K/32, R) uint8 view with unit column stride")
+    _chk(lib().chadavit_mx8_quantize(_ptr(x), c_int(x.stride(0)), _ptr(q), _ptr(scales), c_int(scales.stride(0)), c_int(R), c_int(K),
+                                     c_int(1 if relu else 0), _stream()), "chadavit_mx8_quantize")
     return q, scales
 
 
 @_timed(lambda xq, xs, wq, ws, *a, **k: ("gemm_nt_mx8", xq.shape[0], wq.shape[0], xq.shape[1], k.get("epilogue", 0)))
 def gemm_nt_mx8(xq, xs, wq, ws, bias=None, epilogue=EPI_NONE, aux=None, out=None):
     """out[M,N] bf16 = epilogue(deq(xq, xs) @ deq(wq, ws)^T + bias) on the MX-scaled fp8 MFMA (epilogues NONE / RELU / RESID)."""
-    for t, nm in ((xq, "xq"), (xs, "xs"), (wq, "wq"), (ws, "ws")):
-        _req(t, U8, nm)
+    _req(xq, U8, "xq"); _req(wq, U8, "wq")
     M, K = xq.shape
     N = wq.shape[0]
-    if wq.shape[1] != K or tuple(xs.shape) != (K // 32, M) or tuple(ws.shape) != (K // 32, N):
-        raise RuntimeError("gemm_nt_mx8: operand / scale shapes do not match")
+    for t, nm, rows in ((xs, "xs", M), (ws, "ws", N)):
+        if t.dtype != U8 or t.device != xq.device or t.stride(1) != 1 or tuple(t.shape) != (K // 32, rows):
+            raise RuntimeError(f"gemm_nt_mx8: {nm} must be the (K/32, rows) uint8 scale view mx8_quantize returns")
+    if wq.shape[1] != K:
+        raise RuntimeError("gemm_nt_mx8: operand shapes do not match")
     if out is None:
         out = torch.empty((M, N), device=xq.device, dtype=BF16)
     _req(out, BF16, "out")
@@ -676,8 +681,9 @@ def gemm_nt_mx8(xq, xs, wq, ws, bias=None, epilogue=EPI_NONE, aux=None, out=None
         _req(bias, F32, "bias")
     if aux is not None:
         _req(aux, BF16, "aux")
-    rc = lib().chadavit_gemm_nt_mx8(_ptr(xq), _ptr(xs), _ptr(wq), _ptr(ws), _ptr(out), c_int(out.stride(0)), c_int(M), c_int(N), c_int(K),
-                                    _ptr(bias), c_int(epilogue), _ptr(aux), c_int(aux.stride(0) if aux is not None else 0), _stream())
+    rc = lib().chadavit_gemm_nt_mx8(_ptr(xq), _ptr(xs), c_int(xs.stride(0)), _ptr(wq), _ptr(ws), c_int(ws.stride(0)), _ptr(out),
+                                    c_int(out.stride(0)), c_int(M), c_int(N), c_int(K), _ptr(bias), c_int(epilogue), _ptr(aux),
+                                    c_int(aux.stride(0) if aux is not None else 0), _stream())
     _chk(rc, "chadavit_gemm_nt_mx8")
     return out
 

@@ -275,13 +275,13 @@ int chadavit_sum_rows_f32(const float* x, float* out, int rows, int cols, float 
  * OCP MX fp8: e4m3fn elements + one E8M0 power-of-two scale per 32 consecutive k of a row (the form gfx950's
  * v_mfma_scale_f32_16x16x128_f8f6f4 multiplies at twice the bf16 MFMA rate).  Replaces the nn.Linear forwards of the encoder block
  * (src/backbones/vit/chada_vit.py:95-116) when ChAdaViT.weight_dtype == "fp8".
- * chadavit_mx8_quantize: x bf16 [R, K] (row stride ldx) -> q [R, K] e4m3 bytes (16-byte aligned), scales [K/32, R] E8M0 bytes;
- *   relu != 0 applies max(x, 0) first (the FFN's hidden activation).  K % 32 == 0. */
-int chadavit_mx8_quantize(const chada_bf16* x, int ldx, void* q, void* scales, int R, int K, int relu, void* stream);
+ * chadavit_mx8_quantize: x bf16 [R, K] (row stride ldx) -> q [R, K] e4m3 bytes (16-byte aligned), scales [K/32, lds] E8M0 bytes
+ *   (row stride lds >= R, a multiple of 4; 4-byte aligned); relu != 0 applies max(x, 0) first.  K % 32 == 0. */
+int chadavit_mx8_quantize(const chada_bf16* x, int ldx, void* q, void* scales, int lds, int R, int K, int relu, void* stream);
 /* Out[M,N] (bf16) = epilogue(deq(Xq, xs) deq(Wq, ws)^T + bias); epilogue 0 = none, 1 = ReLU, 3 = + aux (bf16 [M, N], ld ldaux).
- * N % 128 == 0, K % 128 == 0. */
-int chadavit_gemm_nt_mx8(const void* Xq, const void* xs, const void* Wq, const void* ws, chada_bf16* Out, int ldo, int M, int N, int K,
-                         const float* bias, int epilogue, const chada_bf16* aux, int ldaux, void* stream);
+ * xs [K/32, lds_x], ws [K/32, lds_w] as written by chadavit_mx8_quantize.  N % 128 == 0, K % 128 == 0. */
+int chadavit_gemm_nt_mx8(const void* Xq, const void* xs, int lds_x, const void* Wq, const void* ws, int lds_w, chada_bf16* Out, int ldo,
+                         int M, int N, int K, const float* bias, int epilogue, const chada_bf16* aux, int ldaux, void* stream);
 
 /* ---- device side of the multi-crop augmentation contract (build_transform_pipeline, src/data/pretrain_dataloader.py:272-328) -------
  * chadavit_crop_resize: RandomResizedCrop / Resize with cv2.INTER_CUBIC (+ CustomColorJitter, src/data/custom_transforms.py:301-351,
