@@ -327,8 +327,9 @@ def replay_launches(counts, nch, wl, dev, reps=10):
             hh = torch.empty((M, FF_), device=dev, dtype=bf) if wh else None
             zz = torch.empty((M, D_), device=dev, dtype=bf) if wh else None
             sa = (torch.empty(M, device=dev), torch.empty(M, device=dev)) if wh else None
+            rb_ = ops.relu_bits_buffer(M, FF_, dev) if wh else None
             fn = lambda: ops.ffn_ln_fwd(x, pk, b1_, b2_, (gg, bb_, 1e-5), resid=x, z=zz, h=hh, ln_b=(gg, bb_, 1e-5) if two else None,
-                                        stats_a=sa, stats_b=sa if two else None)
+                                        stats_a=sa, stats_b=sa if two else None, relu_bits=rb_)
         elif name == "proj_ffn_ln_fwd":
             _, M, D_, FF_, wh, two, fq, wb = key
             a_ = torch.randn((M, D_), device=dev).to(bf)

@@ -333,9 +333,10 @@ def _block_fwd(m: ChAdaViT, flat: FlatParams, i: int, x, rb: RaggedBatch, save: 
         # one kernel: FFN with the hidden activation on chip (written out only when saving) + norm2 + the next block's norm1
         hid = torch.empty((T, flat.shapes[b + "linear1.weight"][0]), device=dev, dtype=torch.bfloat16) if save else None
         z = torch.empty((T, x1.shape[1]), device=dev, dtype=torch.bfloat16) if save else None
+        rbits = ops.relu_bits_buffer(T, flat.shapes[b + "linear1.weight"][0], dev) if (save and flat.ffn_packed_bwd(b + "linear1.weight") is not None) else None
         x2, h_next = ops.ffn_ln_fwd(x1, pk, flat.f(b + "linear1.bias"), flat.f(b + "linear2.bias"), ln2, resid=x1, z=z, h=hid,
                                     ln_b=None if last else ln1n, stats_a=(st[4], st[5]) if save else None,
-                                    stats_b=(st_next[0], st_next[1]) if (save and not last) else None)
+                                    stats_b=(st_next[0], st_next[1]) if (save and not last) else None, relu_bits=rbits)
     else:
         hid = _linear(m, flat, x1, b + "linear1.weight", flat.f(b + "linear1.bias"), ops.EPI_RELU)
         z = _linear(m, flat, hid, b + "linear2.weight", flat.f(b + "linear2.bias"), ops.EPI_RESID, x1)

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libchadavit_hip.so")
-SOURCES = ["gemm_nt.hip", "ffn_fused.hip", "gemm_tn.hip", "layernorm.hip", "attention.hip", "tokenizer.hip", "dino_ops.hip", "gemm_mx8.hip", "augment.hip"]
+SOURCES = ["gemm_nt.hip", "ffn_fused.hip", "ffn_fused_d384.hip", "gemm_tn.hip", "layernorm.hip", "attention.hip", "tokenizer.hip", "dino_ops.hip", "gemm_mx8.hip", "augment.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
@@ -40,7 +40,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
         sp = os.path.join(CSRC, src)
         op = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(op)
-        if force or _stale(op, [sp] + headers):
+        deps = [sp] + headers + ([os.path.join(CSRC, "ffn_fused.hip")] if src == "ffn_fused_d384.hip" else [])
+        if force or _stale(op, deps):
             jobs.append([hipcc, *FLAGS, "-c", sp, "-o", op])
 
     def run(cmd):

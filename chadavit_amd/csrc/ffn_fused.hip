@@ -18,10 +18,28 @@
 //     independent, so the MFMA pipe never waits for the bias/ReLU/convert step in between.
 #include "common.h"
 
+// This file is compiled twice: as is (D = 192, 4 waves x 32 rows, with the whole-block prologue / postlogue) and from
+// ffn_fused_d384.hip with FFN_FD = 384 (Small): 8 waves x 16 rows per block -- the X fragments (12 k-steps) and the 16 x 384 output
+// accumulators of ONE 16-row tile are the same 144 registers as two tiles at D = 192, the 48 KiB weight blocks of a chunk are
+// shared by eight waves (three stages = 144 KiB: one block per CU).  The secondary build exports its launchers under internal
+// names (chada_int_*_d384); the public entry points below dispatch on D.
+#ifndef FFN_FD
+#define FFN_FD 192
+#define FFN_NW 4
+#define FFN_RT 2
+#define FFN_PRIMARY 1
+#define FFN_NAME(x) chadavit_##x
+#else
+#define FFN_PRIMARY 0
+#define FFN_NAME(x) chada_int_##x##_d384
+#endif
+
 namespace {
 using namespace chada;
 
-constexpr int FD = 192;                 // model width this kernel is specialised for
+constexpr int FD = FFN_FD;              // model width this build is specialised for
+constexpr int NWV = FFN_NW;             // waves per block
+constexpr int DRT = FFN_RT;             // 16-row tiles per wave of the default instances
 constexpr int HC = 32;                  // hidden units per chunk
 constexpr int KS1 = FD / 32;            // k-steps of GEMM1
 constexpr int NT2 = FD / 16;            // output column tiles of GEMM2
@@ -144,10 +162,10 @@ __device__ __forceinline__ void ffn_core(BufRsrc wrs, unsigned blk_bytes, bf16_t
   constexpr int HROW = 72;
   constexpr int NPEND = WRITE_H ? RT * 2 : 1;
   const int li = l & 15, g = l >> 4;
-  if (issue) {  // record f of a block goes to wave f & 3
+  if (issue) {  // record f of a block goes to wave f % NWV
 #pragma unroll
-    for (int i = 0; i < BLK_FRAGS / 4; ++i) {
-      const int f = w + 4 * i;
+    for (int i = 0; i < BLK_FRAGS / NWV; ++i) {
+      const int f = w + NWV * i;
       lds_dma16(wrs, dst + f * FRAG_ELEMS, l * 16, blk_bytes + f * (FRAG_ELEMS * 2));
     }
   }
@@ -221,7 +239,7 @@ __device__ __forceinline__ void ffn_core(BufRsrc wrs, unsigned blk_bytes, bf16_t
     __builtin_amdgcn_sched_barrier(0);
   }
   if constexpr (DO_G1) {
-    if constexpr (MODE == 1) rbits = 0u;
+    if constexpr (MODE == 1) rbits = 0u;  // 8 RT bits per chunk
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
@@ -255,7 +273,7 @@ __device__ __forceinline__ void ffn_core(BufRsrc wrs, unsigned blk_bytes, bf16_t
 // l holds the 16 bits of chunk k (low half: even k) described at ffn_core.  M/32 tiles x FF/256 groups x 1 KiB = M * FF / 8 bytes,
 // written as whole 1 KiB records; the backward dX instance reads it with the same lane mapping, nothing else looks inside.
 template <int RT, bool WRITE_H, bool PRO = false, int MODE = 0>
-__global__ __launch_bounds__(256, (RT <= 2 ? 2 : 1)) void ffn_fwd_kernel(const bf16_t* __restrict__ X, int ldx,
+__global__ __launch_bounds__(64 * NWV, (RT * NWV <= 8 ? 2 : 1)) void ffn_fwd_kernel(const bf16_t* __restrict__ X, int ldx,
                                                                          const bf16_t* __restrict__ packed,
                                                                          const float* __restrict__ b1,
                                                                          const float* __restrict__ b2,
@@ -263,8 +281,9 @@ __global__ __launch_bounds__(256, (RT <= 2 ? 2 : 1)) void ffn_fwd_kernel(const b
                                                                          bf16_t* __restrict__ Out, int ldo,
                                                                          bf16_t* __restrict__ H, int ldh, int M, int FF, FfnLnTail ln,
                                                                          FfnPro pro, unsigned* __restrict__ RB) {
-  static_assert(MODE == 0 || RT == 2, "the ReLU-bit record layout is defined for 32 rows per wave");
+  static_assert(MODE == 0 || RT <= 2, "the ReLU-bit record layout is defined for 16 or 32 rows per wave");
   static_assert(!(MODE == 2 && PRO), "the backward instance has no prologue");
+  static_assert(!PRO || (FD == 192 && NWV == 4), "the prologue / postlogue exist for D = 192 only");
   constexpr int STAGE = BLK_FRAGS * FRAG_ELEMS;  // bf16 elements per stage (25 KiB)
   // forward-only instance: THREE stages, the LDS-DMA of block k+2 is issued while block k is consumed and the wait at a
   // barrier is counted (vmcnt(6): only the six DMA instructions of the newest block may still be in flight -- loads retire
@@ -272,7 +291,7 @@ __global__ __launch_bounds__(256, (RT <= 2 ? 2 : 1)) void ffn_fwd_kernel(const b
   constexpr int NST = WRITE_H ? 2 : 3;
   // ONE __shared__ object, carved by hand: with several, the LDS lowering tags every access with per-variable alias scopes
   // that replace the finer ones ffn_core's __restrict__ pointers produce (see there)
-  constexpr int SH_ELEMS = WRITE_H ? 4 * 16 * RT * 72 : 0;
+  constexpr int SH_ELEMS = WRITE_H ? NWV * 16 * RT * 72 : 0;
   __shared__ __attribute__((aligned(16))) bf16_t smem[NST * STAGE + 2 * MAX_FF + SH_ELEMS];
   float* const sB1 = reinterpret_cast<float*>(smem + NST * STAGE);
   // WRITE_H: per-wave slab where two consecutive hidden chunks (64 units = 128 B per row) are gathered before they are
@@ -284,39 +303,54 @@ __global__ __launch_bounds__(256, (RT <= 2 ? 2 : 1)) void ffn_fwd_kernel(const b
   const int tid = threadIdx.x, l = tid & 63, li = l & 15, g = l >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int NC = FF / HC;
-  const int m0 = blockIdx.x * (64 * RT) + w * (16 * RT);
+  const int m0 = blockIdx.x * (NWV * 16 * RT) + w * (16 * RT);
 
   bf16x8 hb[RT];
   bf16x8 pend[NPEND];
   // ReLU-bit plumbing (see RB above): four named dwords, selected with uniform branches (a runtime-indexed vector would go to
   // scratch)
+  // a chunk has 8 RT bits per lane: CPD chunks share a dword, a record of 8 chunks is NDW dwords per lane (RT = 2: 4 x 16 bytes = the
+  // 1 KiB record of the header comment; RT = 1: 2 dwords, 512-byte records -- M * FF / 8 bytes either way)
+  constexpr int BPC = 8 * RT, CPD = 32 / BPC, NDW = 8 / CPD;
+  static_assert(MODE == 0 || NDW == 4 || NDW == 2, "record = 2 or 4 dwords per lane");
   unsigned rbits = 0u, mw0 = 0u, mw1 = 0u, mw2 = 0u, mw3 = 0u;
-  u32x4* const rb_rec = (MODE != 0 && RB != nullptr)
-                            ? reinterpret_cast<u32x4*>(RB) + ((size_t)(blockIdx.x * 4 + w) * (size_t)(FF / (8 * HC))) * 64 + l
-                            : nullptr;
-  u32x4 mnext = {0u, 0u, 0u, 0u};
-  if constexpr (MODE == 2) mnext = rb_rec[0];
+  unsigned* const rb_rec = (MODE != 0 && RB != nullptr)
+                               ? RB + (((size_t)(blockIdx.x * NWV + w) * (size_t)(FF / (8 * HC))) * 64 + l) * NDW
+                               : nullptr;
+  auto rec_load = [&](int rec, unsigned (&d)[4]) {
+    if constexpr (NDW == 4) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(rb_rec + (size_t)rec * 64 * NDW);
+      d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+    } else {
+      const u32x2 v = *reinterpret_cast<const u32x2*>(rb_rec + (size_t)rec * 64 * NDW);
+      d[0] = v[0]; d[1] = v[1]; d[2] = 0u; d[3] = 0u;
+    }
+  };
+  unsigned mnext[4] = {0u, 0u, 0u, 0u};
+  if constexpr (MODE == 2) rec_load(0, mnext);
   auto mask_pre = [&](int k) {   // MODE 2: the bits of chunk k, in front of its GEMM1; the next record is requested 8 chunks ahead
     if constexpr (MODE == 2) {
       if ((k & 7) == 0) {
         mw0 = mnext[0]; mw1 = mnext[1]; mw2 = mnext[2]; mw3 = mnext[3];
-        if (k + 8 < FF / HC) mnext = rb_rec[(size_t)((k >> 3) + 1) * 64];
+        if (k + 8 < FF / HC) rec_load((k >> 3) + 1, mnext);
       }
-      const int q = (k >> 1) & 3;
+      const int q = (k & 7) / CPD;
       const unsigned v = q == 0 ? mw0 : q == 1 ? mw1 : q == 2 ? mw2 : mw3;
-      rbits = (k & 1) ? (v >> 16) : (v & 0xFFFFu);
+      rbits = (v >> ((k % CPD) * BPC)) & ((1u << BPC) - 1u);
     }
   };
   auto mask_post = [&](int k) {  // MODE 1: file the bits GEMM1 of chunk k just produced; a full record leaves every 8 chunks
     if constexpr (MODE == 1) {
-      const int q = (k >> 1) & 3;
-      const unsigned add = (k & 1) ? (rbits << 16) : rbits;
-      if (q == 0) mw0 = (k & 1) ? (mw0 | add) : add;
-      else if (q == 1) mw1 = (k & 1) ? (mw1 | add) : add;
-      else if (q == 2) mw2 = (k & 1) ? (mw2 | add) : add;
-      else mw3 = (k & 1) ? (mw3 | add) : add;
-      if ((k & 7) == 7 && rb_rec != nullptr)
-        __builtin_nontemporal_store(u32x4{mw0, mw1, mw2, mw3}, rb_rec + (size_t)(k >> 3) * 64);
+      const int q = (k & 7) / CPD, sh = (k % CPD) * BPC;
+      const unsigned add = rbits << sh;
+      if (q == 0) mw0 = sh ? (mw0 | add) : add;
+      else if (q == 1) mw1 = sh ? (mw1 | add) : add;
+      else if (q == 2) mw2 = sh ? (mw2 | add) : add;
+      else mw3 = sh ? (mw3 | add) : add;
+      if ((k & 7) == 7 && rb_rec != nullptr) {
+        if constexpr (NDW == 4) __builtin_nontemporal_store(u32x4{mw0, mw1, mw2, mw3}, reinterpret_cast<u32x4*>(rb_rec + (size_t)(k >> 3) * 64 * NDW));
+        else __builtin_nontemporal_store(u32x2{mw0, mw1}, reinterpret_cast<u32x2*>(rb_rec + (size_t)(k >> 3) * 64 * NDW));
+      }
     }
   };
   // (no LDS read follows the first block's DMA before the barrier: issued bare)
@@ -324,9 +358,9 @@ __global__ __launch_bounds__(256, (RT <= 2 ? 2 : 1)) void ffn_fwd_kernel(const b
   constexpr int J3 = PRO ? 3 : 0;   // stream blocks in front of FFN block 0
   constexpr int LA = NST - 1;       // DMA look-ahead in blocks
 #pragma unroll
-  for (int i = 0; i < BLK_FRAGS / 4; ++i) lds_dma16(wrs, smem + (w + 4 * i) * FRAG_ELEMS, l * 16, (w + 4 * i) * (FRAG_ELEMS * 2));
+  for (int i = 0; i < BLK_FRAGS / NWV; ++i) lds_dma16(wrs, smem + (w + NWV * i) * FRAG_ELEMS, l * 16, (w + NWV * i) * (FRAG_ELEMS * 2));
   if constexpr (MODE != 2)
-    for (int i = tid; i < FF / 4; i += 256) reinterpret_cast<f32x4*>(sB1)[i] = reinterpret_cast<const f32x4*>(b1)[i];
+    for (int i = tid; i < FF / 4; i += 64 * NWV) reinterpret_cast<f32x4*>(sB1)[i] = reinterpret_cast<const f32x4*>(b1)[i];
 
   bf16x8 xf[RT][KS1];
   int mrow[RT];
@@ -495,7 +529,7 @@ __global__ __launch_bounds__(256, (RT <= 2 ? 2 : 1)) void ffn_fwd_kernel(const b
   float* const sLn = sB1;  // the bias slab is dead now: gamma / beta of the tail are staged there ([ga | ba | gb | bb], FD each)
   if (ln.mode) {
     __syncthreads();
-    for (int i = tid; i < FD; i += 256) {
+    for (int i = tid; i < FD; i += 64 * NWV) {
       sLn[i] = ln.ga[i];
       sLn[FD + i] = ln.ba[i];
       if (ln.mode == 2) { sLn[2 * FD + i] = ln.gb[i]; sLn[3 * FD + i] = ln.bb[i]; }
@@ -638,12 +672,35 @@ __global__ __launch_bounds__(256, (RT <= 2 ? 2 : 1)) void ffn_fwd_kernel(const b
 
 }  // namespace
 
-extern "C" long long chadavit_ffn_packed_bytes(int D, int FF) {
+#if FFN_PRIMARY
+// the D = 384 build of this file (ffn_fused_d384.hip)
+extern "C" long long chada_int_ffn_packed_bytes_d384(int D, int FF);
+extern "C" int chada_int_ffn_pack_d384(const chada_bf16* W1, const chada_bf16* W2, void* packed, int D, int FF, void* stream);
+extern "C" int chada_int_ffn_pack_batched_d384(const chada_bf16* slab, void* packed, const long long* desc, int n_layers, int D, int FF,
+                                               void* stream);
+extern "C" int chada_int_ffn_fwd_d384(const chada_bf16* X, int ldx, const void* packed, const float* b1, const float* b2,
+                                      const chada_bf16* resid, int ldr, chada_bf16* Out, int ldo, chada_bf16* H, int ldh, void* relu_bits,
+                                      int M, int D, int FF, int rows_per_wave, void* stream);
+extern "C" int chada_int_ffn_ln_fwd_d384(const chada_bf16* X, int ldx, const void* packed, const float* b1, const float* b2,
+                                         const chada_bf16* resid, int ldr, chada_bf16* Z, int ldz, chada_bf16* H, int ldh,
+                                         const float* gamma_a, const float* beta_a, float eps_a, chada_bf16* X2, float* mean_a, float* rstd_a,
+                                         const float* gamma_b, const float* beta_b, float eps_b, chada_bf16* Hn, float* mean_b, float* rstd_b,
+                                         void* relu_bits, int M, int D, int FF, void* stream);
+extern "C" int chada_int_ffn_bwd_dx_d384(const chada_bf16* dZ, int lddz, const void* packed_bwd, const void* relu_bits, chada_bf16* dX1,
+                                         int lddx, chada_bf16* dPre, int lddp, int M, int D, int FF, void* stream);
+#define FFN_DISPATCH_384(call) if (D == 384) return call
+#else
+#define FFN_DISPATCH_384(call)
+#endif
+
+extern "C" long long FFN_NAME(ffn_packed_bytes)(int D, int FF) {
+  FFN_DISPATCH_384(chada_int_ffn_packed_bytes_d384(D, FF));
   if (D != FD || FF < 2 * HC || FF > MAX_FF || FF % (2 * HC) != 0) return -1;
   return (long long)(FF / HC + 1) * BLK_FRAGS * FRAG_ELEMS * 2;
 }
 
-extern "C" int chadavit_ffn_pack(const chada_bf16* W1, const chada_bf16* W2, void* packed, int D, int FF, void* stream) {
+extern "C" int FFN_NAME(ffn_pack)(const chada_bf16* W1, const chada_bf16* W2, void* packed, int D, int FF, void* stream) {
+  FFN_DISPATCH_384(chada_int_ffn_pack_d384(W1, W2, packed, D, FF, stream));
   CHADA_ENTRY();
   if (!W1 || !W2 || !packed) return 1;
   if (D != FD || FF < 2 * HC || FF > MAX_FF || FF % (2 * HC) != 0) return 2;
@@ -654,6 +711,7 @@ extern "C" int chadavit_ffn_pack(const chada_bf16* W1, const chada_bf16* W2, voi
   return 0;
 }
 
+#if FFN_PRIMARY
 // [3 Wo blocks | FFN blocks | 9 next-QKV blocks] per layer: desc[5 t ..] = {W1, W2, Wo, next in_proj weight (or -1) offsets (bf16
 // elements into the slab's bf16 shadow), packed offset}.  A [D x D] matrix (Wo, or row slice c of the next in_proj weight) is
 // three blocks; block j, record r = ksl * 12 + n: k-step 2j + ksl of output tile n, rows permuted like W2's.
@@ -714,8 +772,11 @@ extern "C" int chadavit_ffn_pack_proj_batched(const chada_bf16* slab, void* pack
   return 0;
 }
 
-extern "C" int chadavit_ffn_pack_batched(const chada_bf16* slab, void* packed, const long long* desc, int n_layers, int D, int FF,
-                                         void* stream) {
+#endif  // FFN_PRIMARY
+
+extern "C" int FFN_NAME(ffn_pack_batched)(const chada_bf16* slab, void* packed, const long long* desc, int n_layers, int D, int FF,
+                                          void* stream) {
+  FFN_DISPATCH_384(chada_int_ffn_pack_batched_d384(slab, packed, desc, n_layers, D, FF, stream));
   CHADA_ENTRY();
   if (!slab || !packed || !desc || n_layers <= 0) return 1;
   if (D != FD || FF < 2 * HC || FF > MAX_FF || FF % (2 * HC) != 0) return 2;
@@ -734,7 +795,7 @@ int launch_ffn(const chada_bf16* X, int ldx, const void* packed, const float* b1
   if (D != FD || FF < 2 * HC || FF > MAX_FF || FF % (2 * HC) != 0 || ldx % 8 != 0 || (Out && ldo % 8 != 0) || (resid && ldr % 8 != 0) ||
       (H && ldh % 8 != 0))
     return 2;
-  if (relu_bits && (FF % (8 * HC) != 0 || rows_per_wave != 32 || ((uintptr_t)relu_bits & 15) != 0)) return 2;
+  if (relu_bits && (FF % (8 * HC) != 0 || rows_per_wave == 64 || ((uintptr_t)relu_bits & 15) != 0)) return 2;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const bf16_t* x = reinterpret_cast<const bf16_t*>(X);
   const bf16_t* pk = reinterpret_cast<const bf16_t*>(packed);
@@ -742,20 +803,28 @@ int launch_ffn(const chada_bf16* X, int ldx, const void* packed, const float* b1
   bf16_t* o = reinterpret_cast<bf16_t*>(Out);
   bf16_t* h = reinterpret_cast<bf16_t*>(H);
   unsigned* rb = reinterpret_cast<unsigned*>(relu_bits);
-#define FFN_LAUNCH(RT, WH, PR, MD)                                                                                      \
-  hipLaunchKernelGGL((ffn_fwd_kernel<RT, WH, PR, MD>), dim3((M + 64 * RT - 1) / (64 * RT)), dim3(256), 0, s, x, ldx, pk, b1, b2, rs, \
-                     ldr, o, ldo, h, ldh, M, FF, ln, (PR ? *pro : FfnPro{}), rb)
+#define FFN_LAUNCH(RT, WH, PR, MD)                                                                                             \
+  hipLaunchKernelGGL((ffn_fwd_kernel<RT, WH, PR, MD>), dim3((M + NWV * 16 * RT - 1) / (NWV * 16 * RT)), dim3(64 * NWV), 0, s, x, ldx, pk, \
+                     b1, b2, rs, ldr, o, ldo, h, ldh, M, FF, ln, (PR ? *pro : FfnPro{}), rb)
   if (bwd) {  // dX pass: X = dz, packed = [W2^T | W1^T] stream, H (optional) receives dpre
-    if (h) FFN_LAUNCH(2, true, false, 2); else FFN_LAUNCH(2, false, false, 2);
-  } else if (pro) {  // with the out-proj + norm1 prologue (32 rows per wave only)
+    if (h) FFN_LAUNCH(DRT, true, false, 2); else FFN_LAUNCH(DRT, false, false, 2);
+  } else if (pro) {  // with the out-proj + norm1 prologue (D = 192, 32 rows per wave only)
+#if FFN_PRIMARY
     if (rb) { if (h) FFN_LAUNCH(2, true, true, 1); else FFN_LAUNCH(2, false, true, 1); }
     else { if (h) FFN_LAUNCH(2, true, true, 0); else FFN_LAUNCH(2, false, true, 0); }
+#else
+    return 2;
+#endif
   } else if (rows_per_wave == 64) {
+#if FFN_PRIMARY
     if (h) FFN_LAUNCH(4, true, false, 0); else FFN_LAUNCH(4, false, false, 0);
+#else
+    return 2;
+#endif
   } else if (rb) {
-    if (h) FFN_LAUNCH(2, true, false, 1); else FFN_LAUNCH(2, false, false, 1);
+    if (h) FFN_LAUNCH(DRT, true, false, 1); else FFN_LAUNCH(DRT, false, false, 1);
   } else {
-    if (h) FFN_LAUNCH(2, true, false, 0); else FFN_LAUNCH(2, false, false, 0);
+    if (h) FFN_LAUNCH(DRT, true, false, 0); else FFN_LAUNCH(DRT, false, false, 0);
   }
 #undef FFN_LAUNCH
   CHADA_CHECK_LAUNCH();
@@ -763,24 +832,28 @@ int launch_ffn(const chada_bf16* X, int ldx, const void* packed, const float* b1
 }
 }  // namespace
 
-extern "C" int chadavit_ffn_fwd(const chada_bf16* X, int ldx, const void* packed, const float* b1, const float* b2,
-                                const chada_bf16* resid, int ldr, chada_bf16* Out, int ldo, chada_bf16* H, int ldh, void* relu_bits,
-                                int M, int D, int FF, int rows_per_wave, void* stream) {
+extern "C" int FFN_NAME(ffn_fwd)(const chada_bf16* X, int ldx, const void* packed, const float* b1, const float* b2,
+                                 const chada_bf16* resid, int ldr, chada_bf16* Out, int ldo, chada_bf16* H, int ldh, void* relu_bits,
+                                 int M, int D, int FF, int rows_per_wave, void* stream) {
+  FFN_DISPATCH_384(chada_int_ffn_fwd_d384(X, ldx, packed, b1, b2, resid, ldr, Out, ldo, H, ldh, relu_bits, M, D, FF, rows_per_wave, stream));
   CHADA_ENTRY();
   FfnLnTail ln{};
   return launch_ffn(X, ldx, packed, b1, b2, resid, ldr, Out, ldo, H, ldh, M, D, FF, rows_per_wave, ln, stream, nullptr, relu_bits);
 }
 
-extern "C" long long chadavit_relu_bits_bytes(int M, int FF) {
+#if FFN_PRIMARY
+extern "C" long long chadavit_relu_bits_bytes(int M, int FF) {  // (the same for both builds: 128-row blocks, 1 bit per element)
   if (M <= 0 || FF <= 0 || FF % (8 * HC) != 0) return -1;
   return (long long)((M + 127) / 128) * 4 * (FF / (8 * HC)) * 1024;
 }
+#endif
 
 // dX pass of the FFN backward in one launch, nothing 2048-wide in HBM:  dX1 = dZ + ((dZ W2) * [H > 0]) W1.
 // `packed_bwd` = chadavit_ffn_pack[_batched] applied to (W2^T as "W1", W1^T as "W2"), i.e. to the [FF x D] and [D x FF] transposed
 // bf16 copies; `relu_bits` = what the forward recorded.  dPre (optional, [M x FF]) receives (dZ W2) * [H > 0] for a separate dW1 pass.
-extern "C" int chadavit_ffn_bwd_dx(const chada_bf16* dZ, int lddz, const void* packed_bwd, const void* relu_bits, chada_bf16* dX1,
-                                   int lddx, chada_bf16* dPre, int lddp, int M, int D, int FF, void* stream) {
+extern "C" int FFN_NAME(ffn_bwd_dx)(const chada_bf16* dZ, int lddz, const void* packed_bwd, const void* relu_bits, chada_bf16* dX1,
+                                    int lddx, chada_bf16* dPre, int lddp, int M, int D, int FF, void* stream) {
+  FFN_DISPATCH_384(chada_int_ffn_bwd_dx_d384(dZ, lddz, packed_bwd, relu_bits, dX1, lddx, dPre, lddp, M, D, FF, stream));
   CHADA_ENTRY();
   if (!dZ || !dX1 || !relu_bits) return 1;
   FfnLnTail ln{};
@@ -788,11 +861,13 @@ extern "C" int chadavit_ffn_bwd_dx(const chada_bf16* dZ, int lddz, const void* p
                     const_cast<void*>(relu_bits), true);
 }
 
-extern "C" int chadavit_ffn_ln_fwd(const chada_bf16* X, int ldx, const void* packed, const float* b1, const float* b2,
-                                   const chada_bf16* resid, int ldr, chada_bf16* Z, int ldz, chada_bf16* H, int ldh,
-                                   const float* gamma_a, const float* beta_a, float eps_a, chada_bf16* X2, float* mean_a, float* rstd_a,
-                                   const float* gamma_b, const float* beta_b, float eps_b, chada_bf16* Hn, float* mean_b, float* rstd_b,
-                                   int M, int D, int FF, void* stream) {
+extern "C" int FFN_NAME(ffn_ln_fwd)(const chada_bf16* X, int ldx, const void* packed, const float* b1, const float* b2,
+                                    const chada_bf16* resid, int ldr, chada_bf16* Z, int ldz, chada_bf16* H, int ldh,
+                                    const float* gamma_a, const float* beta_a, float eps_a, chada_bf16* X2, float* mean_a, float* rstd_a,
+                                    const float* gamma_b, const float* beta_b, float eps_b, chada_bf16* Hn, float* mean_b, float* rstd_b,
+                                    void* relu_bits, int M, int D, int FF, void* stream) {
+  FFN_DISPATCH_384(chada_int_ffn_ln_fwd_d384(X, ldx, packed, b1, b2, resid, ldr, Z, ldz, H, ldh, gamma_a, beta_a, eps_a, X2, mean_a, rstd_a,
+                                             gamma_b, beta_b, eps_b, Hn, mean_b, rstd_b, relu_bits, M, D, FF, stream));
   CHADA_ENTRY();
   if (!gamma_a || !beta_a || !X2 || (mean_a == nullptr) != (rstd_a == nullptr) || (mean_b == nullptr) != (rstd_b == nullptr)) return 1;
   if (Hn && (!gamma_b || !beta_b)) return 1;
@@ -802,9 +877,10 @@ extern "C" int chadavit_ffn_ln_fwd(const chada_bf16* X, int ldx, const void* pac
   ln.eps_a = eps_a; ln.eps_b = eps_b;
   ln.X2 = reinterpret_cast<bf16_t*>(X2); ln.Hn = reinterpret_cast<bf16_t*>(Hn);
   ln.mean_a = mean_a; ln.rstd_a = rstd_a; ln.mean_b = mean_b; ln.rstd_b = rstd_b;
-  return launch_ffn(X, ldx, packed, b1, b2, resid, ldr, Z, ldz, H, ldh, M, D, FF, 32, ln, stream);
+  return launch_ffn(X, ldx, packed, b1, b2, resid, ldr, Z, ldz, H, ldh, M, D, FF, 32, ln, stream, nullptr, relu_bits);
 }
 
+#if FFN_PRIMARY
 // Out-proj + residual + norm1 + FFN + norm2 (+ next norm1) of one transformer block in ONE launch (see FfnPro): `packed` is the
 // [Wo | FFN] stream of chadavit_ffn_pack_proj_batched.
 extern "C" int chadavit_block_fwd(const chada_bf16* A, int lda, const chada_bf16* Xres, int ldxr, const void* packed, const float* bo,
@@ -855,3 +931,4 @@ extern "C" int chadavit_block_fwd(const chada_bf16* A, int lda, const chada_bf16
   // the FFN's input rows and its residual are x1: both come from the X fragments the prologue leaves in registers
   return launch_ffn(nullptr, 0, packed, b1, b2, nullptr, 0, Z, ldz, H, ldh, M, D, FF, 32, ln, stream, &pro, relu_bits);
 }
+#endif  // FFN_PRIMARY

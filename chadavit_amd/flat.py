@@ -79,8 +79,8 @@ class FlatParams:
             wq = pair[3] if len(pair) > 3 else None
             if w1 in self.offsets and w2 in self.offsets and (wo is None or wo in self.offsets):
                 ff, d = self.shapes[w1]
-                proj = wo is not None and tuple(self.shapes[wo]) == (d, d)
-                nbytes = ops.ffn_proj_packed_bytes(d, ff) if proj else ops.ffn_packed_bytes(d, ff)
+                proj = wo is not None and tuple(self.shapes[wo]) == (d, d) and ops.ffn_proj_packed_bytes(d, ff) > 0
+                nbytes = ops.ffn_proj_packed_bytes(d, ff) if proj else ops.ffn_packed_bytes(d, ff)  # (D = 384: FFN stream only)
                 if nbytes > 0 and self._pk_shape in (None, (d, ff)) and self._pk_proj in (None, proj):  # one launch packs all layers
                     self._pk_shape, self._pk_proj = (d, ff), proj
                     has_q = proj and wq is not None and wq in self.offsets and tuple(self.shapes[wq]) == (3 * d, d)

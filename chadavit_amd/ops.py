@@ -172,13 +172,13 @@ def relu_bits_buffer(M, FF, device):
     return torch.empty(n, device=device, dtype=torch.uint8)
 
 
-@_timed(lambda dz, packed_bwd, relu_bits, *a, **k: ("ffn_bwd_dx", dz.shape[0], dz.shape[1], (packed_bwd.numel() // 12288 - 1) * 32, k.get("dpre") is not None))
+@_timed(lambda dz, packed_bwd, relu_bits, *a, **k: ("ffn_bwd_dx", dz.shape[0], dz.shape[1], (packed_bwd.numel() // (64 * dz.shape[1]) - 1) * 32, k.get("dpre") is not None))
 def ffn_bwd_dx(dz, packed_bwd, relu_bits, dx1=None, dpre=None):
     """dx1 = dz + ((dz W2) * [H > 0]) W1 in one kernel (H > 0 from the forward's relu_bits); `dpre` (M, FF) optionally receives
     (dz W2) * [H > 0].  packed_bwd: FlatParams.ffn_packed_bwd."""
     _req(dz, BF16, "dz"); _req(packed_bwd, BF16, "packed_bwd"); _req(relu_bits, torch.uint8, "relu_bits")
     M, D = dz.shape
-    FF = (packed_bwd.numel() // 12288 - 1) * 32
+    FF = (packed_bwd.numel() // (64 * D) - 1) * 32
     if dx1 is None:
         dx1 = torch.empty((M, D), device=dz.device, dtype=BF16)
     _req(dx1, BF16, "dx1")
@@ -192,13 +192,13 @@ def ffn_bwd_dx(dz, packed_bwd, relu_bits, dx1=None, dpre=None):
     return dx1
 
 
-@_timed(lambda x, packed, b1, b2, *a, **k: ("ffn_fwd", x.shape[0], x.shape[1], (packed.numel() // 12288 - 1) * 32, k.get("h") is not None))
+@_timed(lambda x, packed, b1, b2, *a, **k: ("ffn_fwd", x.shape[0], x.shape[1], (packed.numel() // (64 * x.shape[1]) - 1) * 32, k.get("h") is not None))
 def ffn_fwd(x, packed, b1, b2, resid=None, out=None, h=None, rows_per_wave=32, relu_bits=None):
     """out = resid + b2 + relu(x W1^T + b1) W2^T in one kernel; `h` (M, FF) receives relu(.) when given, `relu_bits` its sign
     pattern (relu_bits_buffer)."""
     _req(x, BF16, "x"); _req(packed, BF16, "packed"); _req(b1, F32, "b1"); _req(b2, F32, "b2")
     M, D = x.shape
-    FF = (packed.numel() // 12288 - 1) * 32
+    FF = (packed.numel() // (64 * D) - 1) * 32
     if out is None:
         out = torch.empty((M, D), device=x.device, dtype=BF16)
     _req(out, BF16, "out")
@@ -225,13 +225,13 @@ def channel_jitter_(x, shift, gamma, flip=None):
     return x
 
 
-@_timed(lambda x, packed, *a, **k: ("ffn_ln_fwd", x.shape[0], x.shape[1], (packed.numel() // 12288 - 1) * 32, k.get("h") is not None, k.get("ln_b") is not None))
-def ffn_ln_fwd(x, packed, b1, b2, ln_a, resid=None, z=None, h=None, ln_b=None, stats_a=None, stats_b=None):
+@_timed(lambda x, packed, *a, **k: ("ffn_ln_fwd", x.shape[0], x.shape[1], (packed.numel() // (64 * x.shape[1]) - 1) * 32, k.get("h") is not None, k.get("ln_b") is not None))
+def ffn_ln_fwd(x, packed, b1, b2, ln_a, resid=None, z=None, h=None, ln_b=None, stats_a=None, stats_b=None, relu_bits=None):
     """Fused FFN + LayerNorm tail: x2 = LN_a(z), hn = LN_b(x2) (if ln_b), z = resid + b2 + relu(x W1^T + b1) W2^T.
     ln_a / ln_b = (gamma, beta, eps); z / h are written only when given (backward needs them); returns (x2, hn or None)."""
     _req(x, BF16, "x"); _req(packed, BF16, "packed"); _req(b1, F32, "b1"); _req(b2, F32, "b2")
     M, D = x.shape
-    FF = (packed.numel() // 12288 - 1) * 32
+    FF = (packed.numel() // (64 * D) - 1) * 32
     x2 = torch.empty((M, D), device=x.device, dtype=BF16)
     hn = torch.empty((M, D), device=x.device, dtype=BF16) if ln_b is not None else None
     for t, nm in ((resid, "resid"), (z, "z"), (h, "h")):
@@ -246,7 +246,7 @@ def ffn_ln_fwd(x, packed, b1, b2, ln_a, resid=None, z=None, h=None, ln_b=None, s
                                    c_int(resid.stride(0) if resid is not None else 0), _ptr(z), c_int(z.stride(0) if z is not None else 0),
                                    _ptr(h), c_int(h.stride(0) if h is not None else 0), _ptr(ga), _ptr(ba), c_float(ea), _ptr(x2),
                                    _ptr(sa[0]), _ptr(sa[1]), _ptr(gb), _ptr(bb), c_float(eb), _ptr(hn), _ptr(sb[0]), _ptr(sb[1]),
-                                   c_int(M), c_int(D), c_int(FF), _stream())
+                                   _ptr(relu_bits), c_int(M), c_int(D), c_int(FF), _stream())
     _chk(rc, "chadavit_ffn_ln_fwd")
     return x2, hn
 

@@ -221,11 +221,12 @@ int chadavit_knn_vote(const float* sims, long long ld_sims, const int* train_tar
  *   X2 = LN_a(z), z = resid + b2 + relu(X W1^T + b1) W2^T   (norm2, chada_vit.py:100)
  *   Hn = LN_b(X2) when Hn != NULL                            (the NEXT block's norm1, chada_vit.py:96)
  * Z (optional) receives z for the backward, H (optional) relu(.); statistics (optional pairs) are fp32 per row.  Statistics are
- * taken over the bf16-rounded z / X2, as a separate LayerNorm pass would see them.  D = 192 only. */
+ * taken over the bf16-rounded z / X2, as a separate LayerNorm pass would see them.  relu_bits (optional): see
+ * chadavit_relu_bits_bytes.  D = 192 (Tiny) or 384 (Small: 8 waves x 16 rows per block; also chadavit_ffn_fwd / _pack* / _bwd_dx). */
 int chadavit_ffn_ln_fwd(const chada_bf16* X, int ldx, const void* packed, const float* b1, const float* b2, const chada_bf16* resid,
                         int ldr, chada_bf16* Z, int ldz, chada_bf16* H, int ldh, const float* gamma_a, const float* beta_a, float eps_a,
                         chada_bf16* X2, float* mean_a, float* rstd_a, const float* gamma_b, const float* beta_b, float eps_b,
-                        chada_bf16* Hn, float* mean_b, float* rstd_b, int M, int D, int FF, void* stream);
+                        chada_bf16* Hn, float* mean_b, float* rstd_b, void* relu_bits, int M, int D, int FF, void* stream);
 
 /* LARS (src/utils/lars.py:112-167) on a flat slab: tensor t = [offsets[t], offsets[t]+sizes[t]); flags[t] bit 0 = layer-wise
  * scaling + weight decay apply (p.ndim != 1 or not exclude_bias_n_norm), bit 1 = momentum buffer already initialised. */

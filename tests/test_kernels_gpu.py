@@ -162,15 +162,15 @@ def test_proj_ffn_ln_block_kernel_matches_the_separate_kernels(M, save, two):
             assert torch.equal(qkv, ops.gemm_nt(hn, wq, bias=bq)), float((qkv.float() - ops.gemm_nt(hn, wq, bias=bq).float()).abs().max())
 
 
-@pytest.mark.parametrize("M", [1000, 70001, 333, 128])
-def test_ffn_bwd_dx_from_relu_bits(M):
+@pytest.mark.parametrize("M,D", [(1000, 192), (70001, 192), (333, 192), (128, 192), (1000, 384), (33001, 384), (129, 384)])
+def test_ffn_bwd_dx_from_relu_bits(M, D):
     """Backward dX pass of the FFN without a hidden-wide tensor: the forward records 1 bit per hidden activation (relu_bits), the
     backward kernel computes dx1 = dz + ((dz W2) * [H > 0]) W1 in one launch.  Checked against fp32 torch on the same bf16 inputs
     (the mask taken from the H the forward also wrote here), and bit for bit on dpre against the mask itself; recording the bits
     must not change any forward output."""
     from chadavit_amd import ops
     dev = _dev()
-    D, FF = 192, 2048
+    FF = 2048
     x = _rand((M, D), 81, 1.0).bfloat16().to(dev)
     dz = _rand((M, D), 82, 1.0).bfloat16().to(dev)
     w1 = (_rand((FF, D), 83, 1.0) / math.sqrt(D)).bfloat16().to(dev)
@@ -508,13 +508,15 @@ def test_lars_matches_oracle_and_golden():
                                        err_msg=f"{cname} {n}")
 
 
-@pytest.mark.parametrize("M,rpw,write_h", [(77, 32, True), (1000, 32, False), (1000, 64, True), (4099, 32, True), (4099, 64, False)])
-def test_fused_ffn_matches_fp64_and_two_gemm_path(M, rpw, write_h):
+@pytest.mark.parametrize("M,rpw,write_h,D", [(77, 32, True, 192), (1000, 32, False, 192), (1000, 64, True, 192), (4099, 32, True, 192),
+                                             (4099, 64, False, 192), (77, 32, True, 384), (1000, 32, False, 384), (4099, 32, True, 384)])
+def test_fused_ffn_matches_fp64_and_two_gemm_path(M, rpw, write_h, D):
     """ops.ffn_fwd (one kernel, hidden activation on chip) vs fp64 math and vs linear1 -> relu -> linear2 + residual as two
-    GEMM launches (torch.nn.TransformerEncoderLayer feed-forward, chada_vit.py:256-264)."""
+    GEMM launches (torch.nn.TransformerEncoderLayer feed-forward, chada_vit.py:256-264).  D = 384 (Small) is the second build of
+    the kernel: 8 waves x 16 rows per block."""
     from chadavit_amd import ops
     dev = _dev()
-    D, FF = 192, 2048
+    FF = 2048
     gen = torch.Generator(device="cpu").manual_seed(M)
     bf = torch.bfloat16
     x = torch.randn((M, D), generator=gen).to(dev).to(bf)
@@ -538,7 +540,7 @@ def test_fused_ffn_matches_fp64_and_two_gemm_path(M, rpw, write_h):
         assert not torch.isnan(h.float()).any()
         assert (h.double() - h64).abs().max().item() <= 2e-2
         assert (h.float() - h2.float()).abs().max().item() <= 1.6e-2
-    assert ops.ffn_packed_bytes(384, 2048) < 0 and ops.ffn_packed_bytes(192, 2000) < 0
+    assert ops.ffn_packed_bytes(768, 2048) < 0 and ops.ffn_packed_bytes(192, 2000) < 0 and ops.ffn_packed_bytes(384, 2048) > 0
     # no residual
     out_nr = ops.ffn_fwd(x, pk, b1, b2, rows_per_wave=rpw)
     assert (out_nr.double() - (o64 - res.double())).abs().max().item() <= 2.5e-2
@@ -606,13 +608,14 @@ def test_channel_jitter_matches_reference_golden():
     assert np.allclose(sh[:2], a) and np.allclose(gm[:2], b) and fl.sum() == 0
 
 
-@pytest.mark.parametrize("M,save,two", [(77, True, True), (1000, False, True), (4099, True, False), (4099, False, False)])
-def test_fused_ffn_layernorm_tail(M, save, two):
+@pytest.mark.parametrize("M,save,two,D", [(77, True, True, 192), (1000, False, True, 192), (4099, True, False, 192), (4099, False, False, 192),
+                                          (77, True, True, 384), (4099, False, True, 384), (1000, True, False, 384)])
+def test_fused_ffn_layernorm_tail(M, save, two, D):
     """ops.ffn_ln_fwd = ops.ffn_fwd followed by the stand-alone LayerNorm kernels (norm2, and the next block's norm1): same
     z, H bit for bit; X2 / Hn equal up to the fp32 summation order of the row statistics (<= 1 bf16 ulp on a few elements)."""
     from chadavit_amd import ops
     dev = _dev()
-    D, FF = 192, 2048
+    FF = 2048
     gen = torch.Generator(device="cpu").manual_seed(M + 5)
     bf = torch.bfloat16
     x = torch.randn((M, D), generator=gen).to(dev).to(bf)

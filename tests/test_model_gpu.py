@@ -220,7 +220,7 @@ def _assert_block_kernel_dispatch(summary, D, expect_fused):
 _STEP_CASES = [("step_tiny_multicrop", None, "none"), ("step_tiny_c1_clip", None, "none"),
                ("step_tiny_multicrop", 0, "all"), ("step_tiny_c1_clip", 0, "all"),
                ("step_tiny_fused_rows", None, "global"),
-               ("step_small_mixed", None, "none"), ("step_base_c10", None, "none")]
+               ("step_small_mixed", None, "none"), ("step_small_mixed", 0, "small_fused"), ("step_base_c10", None, "none")]
 
 
 @pytest.mark.parametrize("name,fused_min_rows,dispatch", _STEP_CASES)
@@ -257,6 +257,11 @@ def test_training_step_vs_golden_and_oracle(name, fused_min_rows, dispatch):
         model.on_after_backward()
     if D == 192:
         _assert_block_kernel_dispatch(prof.summary(), D, dispatch)
+    elif dispatch == "small_fused":  # D = 384: fused FFN + LayerNorm tail forward (8 waves x 16 rows) and the fused backward dX pass
+        summ = prof.summary()
+        assert sum(v["launches"] for k, v in summ.items() if k[0] == "ffn_ln_fwd") == 36   # student, teacher, local passes
+        assert sum(v["launches"] for k, v in summ.items() if k[0] == "ffn_bwd_dx") == 12
+        assert not [k for k in summ if k[0] == "gemm_nt" and k[2] == 2048 and k[3] == D and k[4] == ops.EPI_RELU]  # no stand-alone linear1
     # ---- loss
     assert abs(loss.item() - float(g["loss"])) <= 2e-2, (loss.item(), float(g["loss"]))
     # ---- gradients vs golden norms and vs oracle tensors
