@@ -81,51 +81,100 @@ __global__ __launch_bounds__(256) void tokbwd_compact_kernel(const bf16_t* __res
     *reinterpret_cast<u32x4*>(dpatch + (size_t)m * D + c) = *reinterpret_cast<const u32x4*>(dtok + (size_t)row * D + c);
   }
 }
-// (2) ONE pass over the patch-token rows of dtok: slot[c][j][:] = sum over the channel instances gc with chan_idx[gc] == c of
-//     dtok[row(gc, j)][:], row(gc, j) = gc * p + j + chan_img[gc] + 1.  Block = (patch position j, channel slot c); the 4 waves
-//     split the instances, a lane owns 4 consecutive columns (8-byte loads), partials meet in LDS.  Everything the tokenizer's
-//     three parameter gradients need is a marginal of this [max_c, p, D] table (1.5 MB at Tiny):
-//       dpos[j] = sum_c slot[c][j]      dchan[c] = sum_j slot[c][j]
-//     (round 1 made four passes with 192-thread serial loops: 0.55 ms per step at cfg2).
-__global__ __launch_bounds__(256) void tokbwd_slot_kernel(const bf16_t* __restrict__ dtok, const int* __restrict__ chan_img,
-                                                          const int* __restrict__ chan_idx, float* __restrict__ slot, int n_chan,
-                                                          int p, int D) {
+// (2) ONE pass over the rows of dtok into a [max_c][p + 1][D] table:
+//       slot[c][j][:]  (j < p) = sum over the channel instances gc with chan_idx[gc] == c of dtok[row(gc, j)][:],
+//                                row(gc, j) = gc * p + j + chan_img[gc] + 1;
+//       slot[c][p][:]          = sum over the images i = c, c + max_c, ... of dtok[cu[i]][:]   (the CLS rows, split max_c ways).
+//     Block = (j, c).  The block first compacts its row list into LDS (one vectorised scan of chan_idx -- blocks of unused slots
+//     leave after it), then the 4 waves walk the list 8 rows at a time with independent loads: the first version walked the
+//     instance list with one dependent load per iteration and was latency-bound (168 us for 58 MB).  A lane owns 4 consecutive
+//     columns (8-byte loads); partials meet in LDS.  Everything the tokenizer's parameter gradients need is a marginal:
+//       dpos[j] = sum_c slot[c][j]      dchan[c] = sum_j slot[c][j]      dcls = sum_c slot[c][p]
+constexpr int TOKB_MAXLIST = 4096;  // rows one (j, c) block can sum: channel instances of one slot / images of one CLS share
+__global__ __launch_bounds__(256) void tokbwd_slot_kernel(const bf16_t* __restrict__ dtok, const int* __restrict__ cu,
+                                                          const int* __restrict__ chan_img, const int* __restrict__ chan_idx,
+                                                          float* __restrict__ slot, int B, int n_chan, int p, int D, int max_c) {
+  __shared__ int rows[TOKB_MAXLIST];
+  __shared__ int wcnt[4];
   __shared__ f32x4 red[4][64];
-  const int j = blockIdx.x, c = blockIdx.y, l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int j = blockIdx.x, c = blockIdx.y, tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+  // ordered compaction (ballot prefix, no atomics): the list -- and with it the summation order -- is the same on every run
+  const int n_items = j < p ? n_chan : (B - c + max_c - 1) / max_c;
+  int n = 0;
+  for (int g0 = 0; g0 < n_items; g0 += 256) {
+    const int idx = g0 + tid;
+    bool hit = false;
+    int row = 0;
+    if (idx < n_items) {
+      if (j < p) {
+        hit = chan_idx[idx] == c;
+        row = idx * p + j + chan_img[idx] + 1;
+      } else {
+        hit = true;
+        row = cu[c + idx * max_c];
+      }
+    }
+    const unsigned long long bal = __ballot(hit);
+    if (l == 0) wcnt[w] = __popcll(bal);
+    __syncthreads();
+    int woff = 0;
+    for (int q = 0; q < w; ++q) woff += wcnt[q];
+    const int at = n + woff + __popcll(bal & ((1ull << l) - 1ull));
+    if (hit && at < TOKB_MAXLIST) rows[at] = row;
+    n += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    __syncthreads();
+  }
+  n = min(n, TOKB_MAXLIST);  // (the launcher rejects batches that could exceed the list)
   for (int d0 = 0; d0 < D; d0 += 256) {
     const int d = d0 + 4 * l;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (d < D) {
-      for (int gc = w; gc < n_chan; gc += 4) {
-        if (chan_idx[gc] != c) continue;  // wave-uniform
-        const bf16x4 v = *reinterpret_cast<const bf16x4*>(dtok + ((size_t)gc * p + j + chan_img[gc] + 1) * D + d);
+      int k = w;
+      for (; k + 28 < n; k += 32) {  // 8 rows per wave and step: independent loads
+        bf16x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const bf16x4*>(dtok + (size_t)rows[k + 4 * u] * D + d);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s[0] += (float)v[u][0]; s[1] += (float)v[u][1]; s[2] += (float)v[u][2]; s[3] += (float)v[u][3]; }
+      }
+      for (; k < n; k += 4) {
+        const bf16x4 v = *reinterpret_cast<const bf16x4*>(dtok + (size_t)rows[k] * D + d);
         s[0] += (float)v[0]; s[1] += (float)v[1]; s[2] += (float)v[2]; s[3] += (float)v[3];
       }
     }
     red[w][l] = s;
     __syncthreads();
     if (w == 0 && d < D)
-      *reinterpret_cast<f32x4*>(slot + ((size_t)c * p + j) * D + d) = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+      *reinterpret_cast<f32x4*>(slot + ((size_t)c * (p + 1) + j) * D + d) = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
     __syncthreads();
   }
 }
-// (3) the marginals + dcls.  Blocks [0, p): dpos rows; [p, p + max_c): dchan rows; block p + max_c: dcls = sum_i dtok[cu[i]].
-__global__ __launch_bounds__(256) void tokbwd_finish_kernel(const float* __restrict__ slot, const bf16_t* __restrict__ dtok,
-                                                            const int* __restrict__ cu, float* __restrict__ dpos,
+// (3) the marginals.  Blocks [0, p): dpos rows; [p, p + max_c): dchan rows; block p + max_c: dcls.
+__global__ __launch_bounds__(256) void tokbwd_finish_kernel(const float* __restrict__ slot, float* __restrict__ dpos,
                                                             float* __restrict__ dchan, float* __restrict__ dcls, int p, int max_c,
-                                                            int B, int D) {
+                                                            int D) {
   __shared__ float red[4][64];
   const int b = blockIdx.x, l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const size_t cs = (size_t)(p + 1) * D;  // table stride between channel slots
   for (int d0 = 0; d0 < D; d0 += 64) {
     const int d = d0 + l;
     float s = 0.f;
     if (d < D) {
       if (b < p) {
-        for (int c = w; c < max_c; c += 4) s += slot[((size_t)c * p + b) * D + d];
+        for (int c = w; c < max_c; c += 4) s += slot[c * cs + (size_t)b * D + d];
       } else if (b < p + max_c) {
-        for (int j = w; j < p; j += 4) s += slot[((size_t)(b - p) * p + j) * D + d];
+        const float* base = slot + (size_t)(b - p) * cs + d;
+        int jj = w;
+        for (; jj + 28 < p; jj += 32) {
+          float v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = base[(size_t)(jj + 4 * u) * D];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; jj < p; jj += 4) s += base[(size_t)jj * D];
       } else {
-        for (int i = w; i < B; i += 4) s += (float)dtok[(size_t)cu[i] * D + d];
+        for (int c = w; c < max_c; c += 4) s += slot[c * cs + (size_t)p * D + d];
       }
     }
     red[w][l] = s;
@@ -206,16 +255,17 @@ extern "C" int chadavit_tokenizer_bwd(const chada_bf16* dtok_, const int* cu_seq
   const int Mp = n_chan * p;
   hipLaunchKernelGGL(tokbwd_compact_kernel, dim3(grid_for((size_t)Mp * D / 8, 8192)), dim3(256), 0, s, dtok, chan_img, dpatch,
                      Mp, p, D);
-  hipLaunchKernelGGL(tokbwd_slot_kernel, dim3(p, max_channels), dim3(256), 0, s, dtok, chan_img, chan_idx, workspace, n_chan, p, D);
-  hipLaunchKernelGGL(tokbwd_finish_kernel, dim3(p + max_channels + 1), dim3(256), 0, s, workspace, dtok, cu_seqlens, dpos, dchan, dcls,
-                     p, max_channels, B, D);
+  if (n_chan > TOKB_MAXLIST || (B + max_channels - 1) / max_channels > TOKB_MAXLIST) return 2;
+  hipLaunchKernelGGL(tokbwd_slot_kernel, dim3(p + 1, max_channels), dim3(256), 0, s, dtok, cu_seqlens, chan_img, chan_idx, workspace, B,
+                     n_chan, p, D, max_channels);
+  hipLaunchKernelGGL(tokbwd_finish_kernel, dim3(p + max_channels + 1), dim3(256), 0, s, workspace, dpos, dchan, dcls, p, max_channels, D);
   CHADA_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" long long chadavit_tokenizer_bwd_workspace_floats(int p, int D, int max_channels) {
   if (p <= 0 || D <= 0 || max_channels <= 0) return -1;
-  return (long long)max_channels * p * D;
+  return (long long)max_channels * (p + 1) * D;
 }
 
 
