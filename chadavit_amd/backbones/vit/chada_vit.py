@@ -107,6 +107,8 @@ class ChAdaViT(nn.Module):
         # is the one checked against the oracle)
         self.fused_min_rows = FUSED_FFN_MIN_ROWS
         self._dw_stream = None
+        # the LayerNorm backward at a block boundary (norm1' of block i, norm2' of block i-1) as one sweep instead of two launches
+        self.fused_ln_pair = True
         # "bf16" (default) or "fp8": the block's four nn.Linear forwards (in_proj, out_proj, linear1, linear2) on the MX-scaled fp8
         # MFMA -- weights AND their input activations quantised to OCP-MX e4m3 (BASELINE.json configs[4], ChAda-ViT-Base); the
         # backward keeps bf16 operands.  Needs embed_dim % 128 == 0.
@@ -349,8 +351,11 @@ def _block_fwd(m: ChAdaViT, flat: FlatParams, i: int, x, rb: RaggedBatch, save: 
     return x2, saved, h_next, st_next, qkv_next
 
 
-def _block_bwd(m: ChAdaViT, flat: FlatParams, i: int, dx2, saved, rb: RaggedBatch, acc: bool, tn_ws, ln_ws, side=None, keep=None):
+def _block_bwd(m: ChAdaViT, flat: FlatParams, i: int, dx2, saved, rb: RaggedBatch, acc: bool, tn_ws, ln_ws, side=None, keep=None,
+               pend=None, defer=False):
     """acc: gradients of this backward call are ADDED to what the flat grad buffer already holds.
+    pend: what block i+1 left undone (its closing norm1 backward, see `defer`) -- then dx2 is None and this block's norm2 backward runs
+    chained behind it in one sweep (ops.layernorm_bwd_pair).  defer: return (None, pend) instead of (dx, None).
     side: optional HIP stream for the weight-gradient (TN) GEMMs -- they only feed the gradient slab, so they run beside
     the dX chain (LN bwd -> GEMM -> attention bwd ...) and fill its grid tails."""
     b = f"blocks.{i}."
@@ -371,8 +376,13 @@ def _block_bwd(m: ChAdaViT, flat: FlatParams, i: int, dx2, saved, rb: RaggedBatc
         with torch.cuda.stream(side):
             ops.gemm_tn(a_t, b_t, G(wname), colsum=G(bname), accumulate=acc, workspace=tn_ws)
 
-    dz = ops.layernorm_bwd(dx2, z, st[4], st[5], flat.f(b + "norm2.weight"), G(b + "norm2.weight"), G(b + "norm2.bias"), ln_ws,
-                           accumulate=acc)
+    if pend is not None:
+        dh_n, x_n, mean_n, rstd_n, g1_n, gw_n, gb_n, dy_n = pend  # x_n is this block's output: LN2(z)
+        dz = ops.layernorm_bwd_pair(dh_n, x_n, mean_n, rstd_n, g1_n, dy_n, z, st[4], st[5], flat.f(b + "norm2.weight"), gw_n, gb_n,
+                                    G(b + "norm2.weight"), G(b + "norm2.bias"), ln_ws, accumulate_a=True, accumulate_b=acc)
+    else:
+        dz = ops.layernorm_bwd(dx2, z, st[4], st[5], flat.f(b + "norm2.weight"), G(b + "norm2.weight"), G(b + "norm2.bias"), ln_ws,
+                               accumulate=acc)
     if rbits is not None:
         # one launch: dH = dz W2 masked by the recorded ReLU pattern, dx1 = dz + dH W1 -- H is not re-read, dH makes no extra trip
         dhid = torch.empty_like(hid)
@@ -392,9 +402,11 @@ def _block_bwd(m: ChAdaViT, flat: FlatParams, i: int, dx2, saved, rb: RaggedBatc
     dh = ops.gemm_nt(dqkv, flat.wt(b + "self_attn.in_proj_weight"))
     dw(dqkv, h, b + "self_attn.in_proj_weight", b + "self_attn.in_proj_bias")
     # norm1 is applied twice in the forward (chada_vit.py:96,99): its gradient gets both contributions
+    if defer:  # ... the second one in the next call, chained in front of block i-1's norm2 backward
+        return None, (dh, x, st[0], st[1], g1, G(b + "norm1.weight"), G(b + "norm1.bias"), dy)
     dx = ops.layernorm_bwd(dh, x, st[0], st[1], g1, G(b + "norm1.weight"), G(b + "norm1.bias"), ln_ws, dres=dy,
                            accumulate=True)
-    return dx
+    return dx, None
 
 
 class _BackboneFn(torch.autograd.Function):
@@ -476,15 +488,21 @@ class _BackboneFn(torch.autograd.Function):
             side = m._dw_stream
             side.wait_stream(main)
         keep = []
+        pair = m.fused_ln_pair and D in ops.LN_PAIR_WIDTHS
+        pend = None
         for i in reversed(range(len(m.blocks))):
-            dx = _block_bwd(m, flat, i, dx, ctx.saved_blocks[i], rb, acc, tn_ws, ln_ws, side, keep)
+            defer = pair and i > 0
+            dx, new_pend = _block_bwd(m, flat, i, dx, ctx.saved_blocks[i], rb, acc, tn_ws, ln_ws, side, keep, pend=pend, defer=defer)
             ctx.saved_blocks[i] = None
             if side is not None and (hook is not None or (i % 3) == 0):
                 main.wait_stream(side)  # weight gradients of the blocks so far are final; their operands may be released
                 keep.clear()
             if hook is not None:
-                b = f"blocks.{i}."
-                hook(flat, *flat.span([b + "self_attn.in_proj_weight", b + "norm2.bias"]))
+                # a block whose closing norm1 backward was deferred is complete only now (its second norm1 contribution just landed)
+                for j in ([i + 1] if pend is not None else []) + ([] if defer else [i]):
+                    b = f"blocks.{j}."
+                    hook(flat, *flat.span([b + "self_attn.in_proj_weight", b + "norm2.bias"]))
+            pend = new_pend
         if side is not None:
             main.wait_stream(side)
             keep.clear()

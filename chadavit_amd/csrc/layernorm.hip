@@ -433,6 +433,97 @@ __global__ __launch_bounds__(256) void ln_bwd_quad_kernel(const bf16_t* __restri
   }
 }
 
+// Two chained LayerNorm backward passes in one sweep: the tail of block i's backward and the head of block i-1's,
+//   dx = LN_a'(dy; x) + dres        (norm1 of block i applied to its input x, plus the residual branch's gradient)
+//   dz = LN_b'(dx; z)               (norm2 of block i-1, whose output IS that input)
+// dx is only ever consumed by the second pass: it stays in registers (rounded to bf16 as the two-launch chain would store it), which
+// takes one write and one read of a [T, D] tensor out of every block boundary of the backward.  Partials: [a: dgamma | dbeta] in
+// partial_a, [b: ...] in partial_b, same layout as ln_bwd_quad_kernel's.
+template <int QD>
+__global__ __launch_bounds__(256) void ln_bwd_pair_quad_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                               const float* __restrict__ mean_a, const float* __restrict__ rstd_a,
+                                                               const float* __restrict__ gamma_a, const bf16_t* __restrict__ dres,
+                                                               const bf16_t* __restrict__ z, const float* __restrict__ mean_b,
+                                                               const float* __restrict__ rstd_b, const float* __restrict__ gamma_b,
+                                                               bf16_t* __restrict__ dz, float* __restrict__ partial_a,
+                                                               float* __restrict__ partial_b, int T) {
+  using QR = QuadRow<QD>;
+  __shared__ float red[4 * QR::RPW][2][QD];
+  const QR q;
+  const int w = threadIdx.x >> 6;
+  f32x4 ga[3], gb[3], dga[3], dba[3], dgb[3], dbb[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    ga[j] = *reinterpret_cast<const f32x4*>(gamma_a + q.col(j));
+    gb[j] = *reinterpret_cast<const f32x4*>(gamma_b + q.col(j));
+    dga[j] = dba[j] = dgb[j] = dbb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  constexpr float invD = 1.0f / QD;
+  for (int row0 = (blockIdx.x * 4 + w) * QR::RPW; row0 < T; row0 += gridDim.x * 4 * QR::RPW) {
+    const int row = row0 + q.rg;
+    const bool live = row < T;
+    const int rr = min(row, T - 1);
+    const float mua = mean_a[rr], rsa = rstd_a[rr], mub = mean_b[rr], rsb = rstd_b[rr];
+    f32x4 xh[3], gg[3], zh[3], rv[3];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const f32x4 xv = ld4(x + (size_t)rr * QD + q.col(j));
+      f32x4 dv = ld4(dy + (size_t)rr * QD + q.col(j));
+      zh[j] = (ld4(z + (size_t)rr * QD + q.col(j)) - mub) * rsb;
+      rv[j] = ld4(dres + (size_t)rr * QD + q.col(j));
+      if (!live) { dv = f32x4{0.f, 0.f, 0.f, 0.f}; rv[j] = dv; }  // rows past T contribute nothing to either pair of column sums
+      xh[j] = (xv - mua) * rsa;
+      gg[j] = dv * ga[j];
+      s1 += hsum(gg[j]);
+      s2 += hsum(gg[j] * xh[j]);
+      dga[j] += dv * xh[j];
+      dba[j] += dv;
+    }
+    s1 = QR::rsum(s1) * invD;
+    s2 = QR::rsum(s2) * invD;
+    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const f32x4 o = (gg[j] - s1 - xh[j] * s2) * rsa + rv[j];
+      const bf16x4 ob = pack4(o[0], o[1], o[2], o[3]);
+      const f32x4 dx = f32x4{(float)ob[0], (float)ob[1], (float)ob[2], (float)ob[3]};  // what the first launch would have stored
+      gg[j] = dx * gb[j];
+      t1 += hsum(gg[j]);
+      t2 += hsum(gg[j] * zh[j]);
+      dgb[j] += dx * zh[j];
+      dbb[j] += dx;
+    }
+    t1 = QR::rsum(t1) * invD;
+    t2 = QR::rsum(t2) * invD;
+    if (live) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const f32x4 o = (gg[j] - t1 - zh[j] * t2) * rsb;
+        *reinterpret_cast<bf16x4*>(dz + (size_t)row * QD + q.col(j)) = pack4(o[0], o[1], o[2], o[3]);
+      }
+    }
+  }
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass) __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      *reinterpret_cast<f32x4*>(&red[w * QR::RPW + q.rg][0][q.col(j)]) = pass ? dgb[j] : dga[j];
+      *reinterpret_cast<f32x4*>(&red[w * QR::RPW + q.rg][1][q.col(j)]) = pass ? dbb[j] : dba[j];
+    }
+    __syncthreads();
+    float* partial = pass ? partial_b : partial_a;
+    for (int c = threadIdx.x; c < 2 * QD; c += 256) {
+      const int which = c / QD, cc = c % QD;
+      float a = 0.f;
+#pragma unroll
+      for (int g = 0; g < 4 * QR::RPW; ++g) a += red[g][which][cc];
+      partial[(size_t)blockIdx.x * 2 * QD + c] = a;
+    }
+  }
+}
+
 // partial [nblk][2*D] -> dgamma|dbeta.  Block = 16 columns x 16 row groups (coalesced 64-byte row segments,
 // 16 independent accumulation chains per column), combined through LDS in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dgamma,
@@ -534,6 +625,36 @@ extern "C" int chadavit_layernorm_bwd(const chada_bf16* dy, const chada_bf16* x,
   CHADA_CHECK_LAUNCH();
   hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * D + 15) / 16), dim3(256), 0, s, workspace, dgamma, dbeta, grid, D,
                      accumulate);
+  CHADA_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int chadavit_layernorm_bwd_pair(const chada_bf16* dy, const chada_bf16* x, const float* mean_a, const float* rstd_a,
+                                           const float* gamma_a, const chada_bf16* dres, const chada_bf16* z, const float* mean_b,
+                                           const float* rstd_b, const float* gamma_b, chada_bf16* dz, float* dgamma_a, float* dbeta_a,
+                                           int accumulate_a, float* dgamma_b, float* dbeta_b, int accumulate_b, int T, int D,
+                                           float* workspace, void* stream) {
+  CHADA_ENTRY();
+  if (!dy || !x || !mean_a || !rstd_a || !gamma_a || !dres || !z || !mean_b || !rstd_b || !gamma_b || !dz || !dgamma_a || !dbeta_a ||
+      !dgamma_b || !dbeta_b || !workspace || T <= 0)
+    return 1;
+  if (D != 192 && D != 384 && D != 768) return 2;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int rpb = 4 * (768 / D);
+  int gq = (T + rpb - 1) / rpb;
+  if (gq > LN_BWD_PARTIALS) gq = LN_BWD_PARTIALS;
+  float* pa = workspace;
+  float* pb = workspace + (size_t)LN_BWD_PARTIALS * 2 * D;
+#define LNPAIR(DV)                                                                                                                      \
+  hipLaunchKernelGGL(ln_bwd_pair_quad_kernel<DV>, dim3(gq), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(dy),                       \
+                     reinterpret_cast<const bf16_t*>(x), mean_a, rstd_a, gamma_a, reinterpret_cast<const bf16_t*>(dres),                \
+                     reinterpret_cast<const bf16_t*>(z), mean_b, rstd_b, gamma_b, reinterpret_cast<bf16_t*>(dz), pa, pb, T)
+  if (D == 192) LNPAIR(192); else if (D == 384) LNPAIR(384); else LNPAIR(768);
+#undef LNPAIR
+  CHADA_CHECK_LAUNCH();
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * D + 15) / 16), dim3(256), 0, s, pa, dgamma_a, dbeta_a, gq, D, accumulate_a);
+  CHADA_CHECK_LAUNCH();
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * D + 15) / 16), dim3(256), 0, s, pb, dgamma_b, dbeta_b, gq, D, accumulate_b);
   CHADA_CHECK_LAUNCH();
   return 0;
 }

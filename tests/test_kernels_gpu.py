@@ -204,6 +204,39 @@ def test_ffn_bwd_dx_from_relu_bits(M, D):
         assert float((dx1.float() - dx_two.float()).abs().max()) <= 3e-2 * float(dx_two.float().abs().max())
 
 
+@pytest.mark.parametrize("T,D", [(1000, 192), (70001, 192), (333, 384), (70, 768), (3, 192)])
+@pytest.mark.parametrize("acc", [False, True])
+def test_layernorm_bwd_pair_equals_two_calls(T, D, acc):
+    """The block-boundary sweep dz = LN_b'(LN_a'(dy; x) + dres; z) against the two layernorm_bwd launches it replaces: the same
+    arithmetic with dx rounded to bf16 in between; the compiler contracts the multiply-adds of the two kernels differently, so dz
+    agrees to one bf16 ulp and the four column sums to fp32 rounding."""
+    from chadavit_amd import ops
+    dev = _dev()
+    z = _rand((T, D), 31, 2.0).bfloat16().to(dev)
+    gb, bb = (1 + _rand((D,), 32, 0.2)).to(dev), _rand((D,), 33, 0.2).to(dev)
+    ga = (1 + _rand((D,), 34, 0.2)).to(dev)
+    st = torch.empty((4, T), device=dev)
+    x = ops.layernorm_fwd(z, gb, bb, 1e-5, mean=st[2], rstd=st[3])          # x = LN_b(z): the next block's input
+    ops.layernorm_fwd(x, ga, torch.zeros_like(ga), 1e-5, mean=st[0], rstd=st[1])
+    dy = _rand((T, D), 35, 1.0).bfloat16().to(dev)
+    dres = _rand((T, D), 36, 1.0).bfloat16().to(dev)
+    ws = ops.layernorm_bwd_workspace(D, dev)
+    init = 0.25 if acc else float("nan")
+    ref = [torch.full((D,), init, device=dev) for _ in range(4)]
+    dx = ops.layernorm_bwd(dy, x, st[0], st[1], ga, ref[0], ref[1], ws, dres=dres, accumulate=acc)
+    dz_ref = ops.layernorm_bwd(dx, z, st[2], st[3], gb, ref[2], ref[3], ws, accumulate=acc)
+    got = [torch.full((D,), init, device=dev) for _ in range(4)]
+    dz = ops.layernorm_bwd_pair(dy, x, st[0], st[1], ga, dres, z, st[2], st[3], gb, got[0], got[1], got[2], got[3], ws,
+                                accumulate_a=acc, accumulate_b=acc)
+    torch.cuda.synchronize()
+    err = (dz.float() - dz_ref.float()).abs()
+    assert bool((err <= 2 ** -7 * dz_ref.float().abs() + 1e-6).all()), float(err.max())   # one bf16 ulp
+    assert float((err > 0).float().mean()) < 0.02   # and almost everywhere identical
+    for a, b in zip(got, ref):
+        assert torch.isfinite(a).all()
+        assert float((a - b).abs().max()) <= 1e-4 * max(float(b.abs().max()), 1.0), float((a - b).abs().max())
+
+
 @pytest.mark.parametrize("T,D", [(1000, 192), (333, 384), (70, 768), (5, 1024)])
 def test_layernorm_fwd_bwd(T, D):
     from chadavit_amd import ops
