@@ -46,6 +46,7 @@ constexpr int NT2 = FD / 16;            // output column tiles of GEMM2
 constexpr int W1_FRAGS = 2 * KS1;       // 12
 constexpr int W2_FRAG0 = W1_FRAGS;      // 12
 constexpr int BLK_FRAGS = W2_FRAG0 + NT2;  // 24 records of 1 KiB per packed block: 6 LDS-DMA instructions per wave
+constexpr int NPB = KS1 / 2;            // stream blocks of a [D x D] projection matrix (two k-steps of all NT2 tiles per block)
 constexpr int MAX_FF = 2048;            // b1 is staged in LDS whole
 constexpr int FRAG_ELEMS = 512;         // bf16 elements per record
 
@@ -137,7 +138,7 @@ struct FfnPro {
   bf16_t* X1; int ldx1;            // norm1(y): FFN input and residual (both taken from registers); optional output
   float* mean1; float* rstd1;      // optional
   // optional POSTLOGUE: the NEXT block's QKV projection of hn = norm1_next(x2), qkv = hn Wqkv^T + bqkv ([M, 3 D]); its weight
-  // follows the FFN blocks in the packed stream as 9 more blocks (three [D x D] row slices packed like Wo), at block qkv_at
+  // follows the FFN blocks in the packed stream as 3 NPB more blocks (three [D x D] row slices packed like Wo), at block qkv_at
   bf16_t* QKV; int ldqkv; const float* bqkv; int qkv_at;
 };
 
@@ -184,8 +185,11 @@ __device__ __forceinline__ void ffn_core(BufRsrc wrs, unsigned blk_bytes, bf16_t
       const int ksl = sidx / (NT2 / 2), n = 2 * (sidx % (NT2 / 2));
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
-        // (k is 0, 1 or 2 at run time: select the fragment with uniform branches so that xf stays in registers)
-        const bf16x8 a = (k == 0) ? xf[rt][ksl] : (k == 1) ? xf[rt][2 + ksl] : xf[rt][4 + ksl];
+        // (k < NPB at run time: select the fragment with uniform branches so that xf stays in registers)
+        bf16x8 a = xf[rt][ksl];
+#pragma unroll
+        for (int kk = 1; kk < NPB; ++kk)
+          if (k == kk) a = xf[rt][2 * kk + ksl];
         oacc[rt][n] = mfma16(pr[sidx & 1][0], a, oacc[rt][n]);
         oacc[rt][n + 1] = mfma16(pr[sidx & 1][1], a, oacc[rt][n + 1]);
       }
@@ -283,7 +287,7 @@ __global__ __launch_bounds__(64 * NWV, (RT * NWV <= 8 ? 2 : 1)) void ffn_fwd_ker
                                                                          FfnPro pro, unsigned* __restrict__ RB) {
   static_assert(MODE == 0 || RT <= 2, "the ReLU-bit record layout is defined for 16 or 32 rows per wave");
   static_assert(!(MODE == 2 && PRO), "the backward instance has no prologue");
-  static_assert(!PRO || (FD == 192 && NWV == 4), "the prologue / postlogue exist for D = 192 only");
+  static_assert(!PRO || RT == DRT, "the prologue / postlogue run on the build's default row tiling");
   constexpr int STAGE = BLK_FRAGS * FRAG_ELEMS;  // bf16 elements per stage (25 KiB)
   // forward-only instance: THREE stages, the LDS-DMA of block k+2 is issued while block k is consumed and the wait at a
   // barrier is counted (vmcnt(6): only the six DMA instructions of the newest block may still be in flight -- loads retire
@@ -355,7 +359,8 @@ __global__ __launch_bounds__(64 * NWV, (RT * NWV <= 8 ? 2 : 1)) void ffn_fwd_ker
   };
   // (no LDS read follows the first block's DMA before the barrier: issued bare)
   const BufRsrc wrs = make_rsrc(packed);
-  constexpr int J3 = PRO ? 3 : 0;   // stream blocks in front of FFN block 0
+  constexpr int J3 = PRO ? NPB : 0;   // stream blocks in front of FFN block 0 (NPB is a multiple of 3: the three-stage ring lines up)
+  static_assert(NPB % 3 == 0, "ring phase of the FFN blocks behind the projection blocks");
   constexpr int LA = NST - 1;       // DMA look-ahead in blocks
 #pragma unroll
   for (int i = 0; i < BLK_FRAGS / NWV; ++i) lds_dma16(wrs, smem + (w + NWV * i) * FRAG_ELEMS, l * 16, (w + NWV * i) * (FRAG_ELEMS * 2));
@@ -406,10 +411,10 @@ __global__ __launch_bounds__(64 * NWV, (RT * NWV <= 8 ? 2 : 1)) void ffn_fwd_ker
       ffn_core<RT, WRITE_H, false, false, false, false, MODE>(wrs, (unsigned)j * (STAGE * 2), smem_o + (j % NST) * STAGE, smem_o, sB1_o, sH_o, true, 0,
                                                  w, l, xf, oacc, hb, pend, rbits);
     bf16x8 rv[RT][NT2 / 2];  // the residual rows: requested before the last projection step, they land under its MFMAs
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < NPB; ++j) {
       if constexpr (NST == 3) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      if (j == 2) {
+      if (j == NPB - 1) {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -630,7 +635,7 @@ __global__ __launch_bounds__(64 * NWV, (RT * NWV <= 8 ? 2 : 1)) void ffn_fwd_ker
   }
   if constexpr (PRO) {
     if (pro.QKV != nullptr && ln.mode == 2) {  // (uniform) the next block's QKV projection of hn, three [M x D] column slices
-      // the ring is free (every wave has passed the barrier in front of the LayerNorm tail): 9 stream blocks, same steps as
+      // the ring is free (every wave has passed the barrier in front of the LayerNorm tail): 3 NPB stream blocks, same steps as
       // the prologue with hn in the X-fragment registers
       auto qblk = [&](int q) { return (unsigned)(pro.qkv_at + q) * (STAGE * 2); };
 #pragma unroll
@@ -642,12 +647,12 @@ __global__ __launch_bounds__(64 * NWV, (RT * NWV <= 8 ? 2 : 1)) void ffn_fwd_ker
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
           for (int n = 0; n < NT2; ++n) oacc[rt][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int j = 0; j < 3; ++j) {
-          const int q = 3 * c + j;
+        for (int j = 0; j < NPB; ++j) {
+          const int q = NPB * c + j;
           if constexpr (NST == 3) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
           else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
           ffn_core<RT, WRITE_H, false, false, false, true, MODE>(wrs, qblk(q + LA), smem_o + ((q + LA) % NST) * STAGE, smem_o + (q % NST) * STAGE,
-                                                           sB1_o, sH_o, q + LA < 9, j, w, l, xf, oacc, hb, pend, rbits);
+                                                           sB1_o, sH_o, q + LA < 3 * NPB, j, w, l, xf, oacc, hb, pend, rbits);
         }
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
@@ -711,20 +716,20 @@ extern "C" int FFN_NAME(ffn_pack)(const chada_bf16* W1, const chada_bf16* W2, vo
   return 0;
 }
 
-#if FFN_PRIMARY
-// [3 Wo blocks | FFN blocks | 9 next-QKV blocks] per layer: desc[5 t ..] = {W1, W2, Wo, next in_proj weight (or -1) offsets (bf16
-// elements into the slab's bf16 shadow), packed offset}.  A [D x D] matrix (Wo, or row slice c of the next in_proj weight) is
-// three blocks; block j, record r = ksl * 12 + n: k-step 2j + ksl of output tile n, rows permuted like W2's.
+// [NPB Wo blocks | FFN blocks | 3 NPB next-QKV blocks] per layer: desc[5 t ..] = {W1, W2, Wo, next in_proj weight (or -1) offsets
+// (bf16 elements into the slab's bf16 shadow), packed offset}.  A [D x D] matrix (Wo, or row slice c of the next in_proj weight) is
+// NPB blocks; block j, record r = ksl * NT2 + n: k-step 2j + ksl of output tile n, rows permuted like W2's.
+namespace {
 __global__ __launch_bounds__(256) void ffn_pack_proj_batched_kernel(const bf16_t* __restrict__ slab, bf16_t* __restrict__ packed,
                                                                     const long long* __restrict__ desc, int FF) {
   const long long* d = desc + 5 * blockIdx.y;
   const int NC = FF / HC;
   const int tid = threadIdx.x;
-  const int xq = (int)blockIdx.x - (NC + 4);  // >= 0: one of the 9 next-QKV blocks
-  if (blockIdx.x < 3 || xq >= 0) {
+  const int xq = (int)blockIdx.x - (NC + 1 + NPB);  // >= 0: one of the 3 NPB next-QKV blocks
+  if ((int)blockIdx.x < NPB || xq >= 0) {
     if (xq >= 0 && d[3] < 0) return;
-    const bf16_t* Wo = xq >= 0 ? slab + d[3] + (size_t)(xq / 3) * FD * FD : slab + d[2];
-    const int j = xq >= 0 ? xq % 3 : blockIdx.x;
+    const bf16_t* Wo = xq >= 0 ? slab + d[3] + (size_t)(xq / NPB) * FD * FD : slab + d[2];
+    const int j = xq >= 0 ? xq % NPB : blockIdx.x;
     bf16_t* blk = packed + d[4] + (size_t)blockIdx.x * BLK_FRAGS * FRAG_ELEMS;
     for (int id = tid; id < BLK_FRAGS * 64; id += 256) {
       const int f = id >> 6, l = id & 63, li = l & 15, g = l >> 4;
@@ -736,8 +741,8 @@ __global__ __launch_bounds__(256) void ffn_pack_proj_batched_kernel(const bf16_t
   }
   const bf16_t* W1 = slab + d[0];
   const bf16_t* W2 = slab + d[1];
-  const int k = blockIdx.x - 3;  // 0..NC
-  bf16_t* blk = packed + d[4] + (size_t)(k + 3) * BLK_FRAGS * FRAG_ELEMS;
+  const int k = blockIdx.x - NPB;  // 0..NC
+  bf16_t* blk = packed + d[4] + (size_t)(k + NPB) * BLK_FRAGS * FRAG_ELEMS;
   for (int id = tid; id < BLK_FRAGS * 64; id += 256) {
     const int f = id >> 6, l = id & 63, li = l & 15, g = l >> 4;
     bf16x8 v;
@@ -755,24 +760,31 @@ __global__ __launch_bounds__(256) void ffn_pack_proj_batched_kernel(const bf16_t
     *reinterpret_cast<bf16x8*>(blk + f * FRAG_ELEMS + l * 8) = v;
   }
 }
+}  // namespace
 
-extern "C" long long chadavit_ffn_proj_packed_bytes(int D, int FF) {  // always with room for the 9 next-QKV blocks
+#if FFN_PRIMARY
+extern "C" long long chada_int_ffn_proj_packed_bytes_d384(int D, int FF);
+extern "C" int chada_int_ffn_pack_proj_batched_d384(const chada_bf16* slab, void* packed, const long long* desc, int n_layers, int D, int FF,
+                                                    void* stream);
+#endif
+
+extern "C" long long FFN_NAME(ffn_proj_packed_bytes)(int D, int FF) {  // always with room for the 3 NPB next-QKV blocks
+  FFN_DISPATCH_384(chada_int_ffn_proj_packed_bytes_d384(D, FF));
   if (D != FD || FF < 2 * HC || FF > MAX_FF || FF % (2 * HC) != 0) return -1;
-  return (long long)(FF / HC + 1 + 3 + 9) * BLK_FRAGS * FRAG_ELEMS * 2;
+  return (long long)(FF / HC + 1 + 4 * NPB) * BLK_FRAGS * FRAG_ELEMS * 2;
 }
 
-extern "C" int chadavit_ffn_pack_proj_batched(const chada_bf16* slab, void* packed, const long long* desc, int n_layers, int D, int FF,
-                                              void* stream) {
+extern "C" int FFN_NAME(ffn_pack_proj_batched)(const chada_bf16* slab, void* packed, const long long* desc, int n_layers, int D, int FF,
+                                               void* stream) {
+  FFN_DISPATCH_384(chada_int_ffn_pack_proj_batched_d384(slab, packed, desc, n_layers, D, FF, stream));
   CHADA_ENTRY();
   if (!slab || !packed || !desc || n_layers <= 0) return 1;
   if (D != FD || FF < 2 * HC || FF > MAX_FF || FF % (2 * HC) != 0) return 2;
-  hipLaunchKernelGGL(ffn_pack_proj_batched_kernel, dim3(FF / HC + 1 + 3 + 9, n_layers), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL(ffn_pack_proj_batched_kernel, dim3(FF / HC + 1 + 4 * NPB, n_layers), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      reinterpret_cast<const bf16_t*>(slab), reinterpret_cast<bf16_t*>(packed), desc, FF);
   CHADA_CHECK_LAUNCH();
   return 0;
 }
-
-#endif  // FFN_PRIMARY
 
 extern "C" int FFN_NAME(ffn_pack_batched)(const chada_bf16* slab, void* packed, const long long* desc, int n_layers, int D, int FF,
                                           void* stream) {
@@ -808,13 +820,9 @@ int launch_ffn(const chada_bf16* X, int ldx, const void* packed, const float* b1
                      b1, b2, rs, ldr, o, ldo, h, ldh, M, FF, ln, (PR ? *pro : FfnPro{}), rb)
   if (bwd) {  // dX pass: X = dz, packed = [W2^T | W1^T] stream, H (optional) receives dpre
     if (h) FFN_LAUNCH(DRT, true, false, 2); else FFN_LAUNCH(DRT, false, false, 2);
-  } else if (pro) {  // with the out-proj + norm1 prologue (D = 192, 32 rows per wave only)
-#if FFN_PRIMARY
-    if (rb) { if (h) FFN_LAUNCH(2, true, true, 1); else FFN_LAUNCH(2, false, true, 1); }
-    else { if (h) FFN_LAUNCH(2, true, true, 0); else FFN_LAUNCH(2, false, true, 0); }
-#else
-    return 2;
-#endif
+  } else if (pro) {  // with the out-proj + norm1 prologue (the build's default row tiling only)
+    if (rb) { if (h) FFN_LAUNCH(DRT, true, true, 1); else FFN_LAUNCH(DRT, false, true, 1); }
+    else { if (h) FFN_LAUNCH(DRT, true, true, 0); else FFN_LAUNCH(DRT, false, true, 0); }
   } else if (rows_per_wave == 64) {
 #if FFN_PRIMARY
     if (h) FFN_LAUNCH(4, true, false, 0); else FFN_LAUNCH(4, false, false, 0);
@@ -881,6 +889,13 @@ extern "C" int FFN_NAME(ffn_ln_fwd)(const chada_bf16* X, int ldx, const void* pa
 }
 
 #if FFN_PRIMARY
+extern "C" int chada_int_block_fwd_d384(const chada_bf16* A, int lda, const chada_bf16* Xres, int ldxr, const void* packed, const float* bo,
+                                        const float* gamma1, const float* beta1, float eps1, chada_bf16* Y, int ldy, chada_bf16* X1, int ldx1,
+                                        float* mean1, float* rstd1, const float* b1, const float* b2, chada_bf16* Z, int ldz, chada_bf16* H,
+                                        int ldh, const float* gamma_a, const float* beta_a, float eps_a, chada_bf16* X2, float* mean_a,
+                                        float* rstd_a, const float* gamma_b, const float* beta_b, float eps_b, chada_bf16* Hn, float* mean_b,
+                                        float* rstd_b, chada_bf16* QKV, int ldqkv, const float* bqkv, void* relu_bits, int M, int D, int FF,
+                                        void* stream);
 // Out-proj + residual + norm1 + FFN + norm2 (+ next norm1) of one transformer block in ONE launch (see FfnPro): `packed` is the
 // [Wo | FFN] stream of chadavit_ffn_pack_proj_batched.
 extern "C" int chadavit_block_fwd(const chada_bf16* A, int lda, const chada_bf16* Xres, int ldxr, const void* packed, const float* bo,
@@ -901,13 +916,18 @@ extern "C" int chadavit_proj_ffn_ln_fwd(const chada_bf16* A, int lda, const chad
                             M, D, FF, stream);
 }
 
+#endif  // FFN_PRIMARY
+
 // ... plus, optionally, the NEXT block's QKV projection (QKV != NULL: needs gamma_b / beta_b; Hn itself becomes optional)
-extern "C" int chadavit_block_fwd(const chada_bf16* A, int lda, const chada_bf16* Xres, int ldxr, const void* packed, const float* bo,
+extern "C" int FFN_NAME(block_fwd)(const chada_bf16* A, int lda, const chada_bf16* Xres, int ldxr, const void* packed, const float* bo,
                                   const float* gamma1, const float* beta1, float eps1, chada_bf16* Y, int ldy, chada_bf16* X1, int ldx1,
                                   float* mean1, float* rstd1, const float* b1, const float* b2, chada_bf16* Z, int ldz, chada_bf16* H,
                                   int ldh, const float* gamma_a, const float* beta_a, float eps_a, chada_bf16* X2, float* mean_a,
                                   float* rstd_a, const float* gamma_b, const float* beta_b, float eps_b, chada_bf16* Hn, float* mean_b,
                                   float* rstd_b, chada_bf16* QKV, int ldqkv, const float* bqkv, void* relu_bits, int M, int D, int FF, void* stream) {
+  FFN_DISPATCH_384(chada_int_block_fwd_d384(A, lda, Xres, ldxr, packed, bo, gamma1, beta1, eps1, Y, ldy, X1, ldx1, mean1, rstd1, b1, b2, Z, ldz, H,
+                                            ldh, gamma_a, beta_a, eps_a, X2, mean_a, rstd_a, gamma_b, beta_b, eps_b, Hn, mean_b, rstd_b, QKV, ldqkv,
+                                            bqkv, relu_bits, M, D, FF, stream));
   CHADA_ENTRY();
   if (QKV && (!gamma_b || !beta_b || !bqkv || ldqkv % 8 != 0)) return 1;
   if (!A || !Xres || !bo || !gamma1 || !beta1 || (mean1 == nullptr) != (rstd1 == nullptr)) return 1;
@@ -927,8 +947,8 @@ extern "C" int chadavit_block_fwd(const chada_bf16* A, int lda, const chada_bf16
   pro.Y = reinterpret_cast<bf16_t*>(Y); pro.ldy = ldy;
   pro.X1 = reinterpret_cast<bf16_t*>(X1); pro.ldx1 = ldx1;
   pro.mean1 = mean1; pro.rstd1 = rstd1;
-  pro.QKV = reinterpret_cast<bf16_t*>(QKV); pro.ldqkv = ldqkv; pro.bqkv = bqkv; pro.qkv_at = FF / HC + 1 + 3;
+  pro.QKV = reinterpret_cast<bf16_t*>(QKV); pro.ldqkv = ldqkv; pro.bqkv = bqkv; pro.qkv_at = FF / HC + 1 + NPB;
   // the FFN's input rows and its residual are x1: both come from the X fragments the prologue leaves in registers
   return launch_ffn(nullptr, 0, packed, b1, b2, nullptr, 0, Z, ldz, H, ldh, M, D, FF, 32, ln, stream, &pro, relu_bits);
 }
-#endif  // FFN_PRIMARY
+

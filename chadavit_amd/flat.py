@@ -97,7 +97,9 @@ class FlatParams:
                 n = ops.ffn_proj_packed_bytes(*self._pk_shape) // 2
                 whole = self._pk_buf[pk_desc[5 * i + 4]:pk_desc[5 * i + 4] + n]
                 self._pkp[w1] = whole
-                self._pk[w1] = whole[3 * 12288:n - 9 * 12288]  # the FFN blocks alone (ops.ffn_fwd / ffn_ln_fwd)
+                d_ = self._pk_shape[0]
+                blk, npb = 64 * d_, d_ // 64  # elements per stream block; blocks per [D x D] projection matrix
+                self._pk[w1] = whole[npb * blk:n - 3 * npb * blk]  # the FFN blocks alone (ops.ffn_fwd / ffn_ln_fwd)
             else:
                 n = ops.ffn_packed_bytes(*self._pk_shape) // 2
                 self._pk[w1] = self._pk_buf[pk_desc[3 * i + 2]:pk_desc[3 * i + 2] + n]

@@ -261,7 +261,7 @@ def ffn_pack_proj_batched(slab, packed, desc, n_layers, D, FF):
          "chadavit_ffn_pack_proj_batched")
 
 
-@_timed(lambda a, xres, packed, *r, **k: ("proj_ffn_ln_fwd", a.shape[0], a.shape[1], (packed.numel() // 12288 - 13) * 32, k.get("h") is not None, k.get("ln_b") is not None, k.get("qkv_bias") is not None, k.get("relu_bits") is not None))
+@_timed(lambda a, xres, packed, *r, **k: ("proj_ffn_ln_fwd", a.shape[0], a.shape[1], (packed.numel() // (64 * a.shape[1]) - 1 - a.shape[1] // 16) * 32, k.get("h") is not None, k.get("ln_b") is not None, k.get("qkv_bias") is not None, k.get("relu_bits") is not None))
 def proj_ffn_ln_fwd(a, xres, packed, bo, ln1, b1, b2, ln_a, y=None, x1=None, stats1=None, z=None, h=None, ln_b=None, stats_a=None,
                     stats_b=None, want_x1=True, qkv_bias=None, qkv=None, want_hn=True, relu_bits=None):
     """One block from the attention output on: y = xres + a Wo^T + bo; x1 = LN1(y); z = x1 + b2 + relu(x1 W1^T + b1) W2^T;
@@ -273,7 +273,7 @@ def proj_ffn_ln_fwd(a, xres, packed, bo, ln1, b1, b2, ln_a, y=None, x1=None, sta
     for t, nm in ((bo, "bo"), (b1, "b1"), (b2, "b2")):
         _req(t, F32, nm)
     M, D = a.shape
-    FF = (packed.numel() // 12288 - 13) * 32
+    FF = (packed.numel() // (64 * D) - 1 - D // 16) * 32   # stream = [D/64 Wo blocks | FF/32 + 1 FFN blocks | 3 D/64 next-QKV blocks] of 64 D elements
     dev = a.device
     if x1 is None and want_x1:
         x1 = torch.empty((M, D), device=dev, dtype=BF16)

@@ -23,7 +23,7 @@ for name, I, J in (("dW1", 2048, 192), ("dW2", 192, 2048)):
     us = t(lambda: ops.gemm_tn(a, b, c, colsum=cs, workspace=ws))
     print(f"{name}: {us:.1f} us  {2.0*M*(I+J)/us/1e6:.2f} TB/s", flush=True)
 M = 254664
-for name, N, K, epi in (("S ffn2", 384, 2048, 3), ("S ffn1", 2048, 384, 1), ("S dH", 2048, 384, 4), ("S qkv", 1152, 384, 0), ("S outproj", 384, 384, 3), ("S dh", 384, 1152, 0)):
+for name, N, K, epi in (("S ffn2", 384, 2048, 3), ("S ffn1", 2048, 384, 1), ("S dH", 2048, 384, 4), ("S qkv", 1152, 384, 0), ("S outproj", 384, 384, 3), ("S dh", 384, 1152, 0), ("S da", 384, 384, 0)):
     x = torch.randn((M, K), device=dev).to(bf); w = (torch.randn((N, K), device=dev) / K ** .5).to(bf)
     bias = torch.zeros(N, device=dev); aux = torch.randn((M, N), device=dev).to(bf) if epi in (3, 4) else None
     o = torch.empty((M, N), device=dev, dtype=bf)

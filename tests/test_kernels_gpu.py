@@ -79,14 +79,16 @@ def test_gemm_tn(T, I, J):
     _close(cs, 2 * a.float().sum(0), 2e-3, 4e-2, "colsum accumulate")
 
 
+@pytest.mark.parametrize("D", [192, 384])
 @pytest.mark.parametrize("M,save,two", [(1000, True, True), (70001, True, True), (4097, False, True), (333, True, False)])
-def test_proj_ffn_ln_block_kernel_matches_the_separate_kernels(M, save, two):
+def test_proj_ffn_ln_block_kernel_matches_the_separate_kernels(M, save, two, D):
     """out-proj + residual + norm1 + FFN + norm2 (+ next norm1) in one launch vs out-proj GEMM, LayerNorm and the fused
     FFN + LayerNorm-tail kernel: y bit for bit, norm1 up to the summation order of its statistics, everything after it bit
     for bit given the same x1 (ragged last panel, both the 3-stage no-H and the 2-stage H instance)."""
     from chadavit_amd import ops
     dev = _dev()
-    D, FF = 192, 2048
+    FF = 2048
+    blk, npb = 64 * D, D // 64   # elements per stream block, blocks per [D x D] projection matrix
     a = _rand((M, D), 51, 1.0).bfloat16().to(dev)
     x = _rand((M, D), 52, 1.0).bfloat16().to(dev)
     wo = (_rand((D, D), 53, 1.0) / math.sqrt(D)).bfloat16().to(dev)
@@ -111,7 +113,7 @@ def test_proj_ffn_ln_block_kernel_matches_the_separate_kernels(M, save, two):
     pkp = torch.empty(n, device=dev, dtype=torch.bfloat16)
     desc = torch.tensor([0, w1.numel(), w1.numel() + w2.numel(), -1, 0], device=dev, dtype=torch.int64)
     ops.ffn_pack_proj_batched(slab, pkp, desc, 1, D, FF)
-    assert torch.equal(pkp[3 * 12288:pkp.numel() - 9 * 12288], pk)
+    assert torch.equal(pkp[npb * blk:pkp.numel() - 3 * npb * blk], pk)
     y = torch.empty((M, D), device=dev, dtype=torch.bfloat16) if save else None
     z = torch.empty((M, D), device=dev, dtype=torch.bfloat16) if save else None
     h = torch.empty((M, FF), device=dev, dtype=torch.bfloat16) if save else None
@@ -152,7 +154,7 @@ def test_proj_ffn_ln_block_kernel_matches_the_separate_kernels(M, save, two):
         pkq = torch.empty(n, device=dev, dtype=torch.bfloat16)
         ops.ffn_pack_proj_batched(slab2, pkq, torch.tensor([0, w1.numel(), w1.numel() + w2.numel(), slab.numel(), 0], device=dev,
                                                            dtype=torch.int64), 1, D, FF)
-        assert torch.equal(pkq[:n - 9 * 12288], pkp[:n - 9 * 12288])
+        assert torch.equal(pkq[:n - 3 * npb * blk], pkp[:n - 3 * npb * blk])
         for want_hn in (True, False):
             x1q, x2q, hnq, qkv = ops.proj_ffn_ln_fwd(a, x, pkq, bo, lns[0], b1, b2, lns[1], ln_b=lns[2], qkv_bias=bq, want_hn=want_hn,
                                                      h=torch.empty_like(h) if save else None)

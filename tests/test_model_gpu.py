@@ -215,7 +215,8 @@ def _assert_block_kernel_dispatch(summary, D, expect_fused):
 # (golden, fused_min_rows override, expected dispatch).  `None` = the default threshold (24576 rows).  The Tiny goldens run
 # twice: on the GEMM + LayerNorm chain their row counts select by default, and with the whole-block kernel forced, so that the
 # dispatch bench.py times is the one held against the reference.  step_tiny_fused_rows is large enough (26282 rows per global
-# pass) to take that dispatch by itself.  step_small_mixed / step_base_c10 put the D = 384 / 768 backward kernels under the
+# pass) to take that dispatch by itself.  step_small_mixed / step_base_c10 put the D = 384 / 768 kernels (for D = 384 with the
+# whole-block forward kernel forced at this size) under the
 # reference (dh = 192 / 384 attention, K = 384 / 768 GEMMs).
 _STEP_CASES = [("step_tiny_multicrop", None, "none"), ("step_tiny_c1_clip", None, "none"),
                ("step_tiny_multicrop", 0, "all"), ("step_tiny_c1_clip", 0, "all"),
@@ -257,9 +258,13 @@ def test_training_step_vs_golden_and_oracle(name, fused_min_rows, dispatch):
         model.on_after_backward()
     if D == 192:
         _assert_block_kernel_dispatch(prof.summary(), D, dispatch)
-    elif dispatch == "small_fused":  # D = 384: fused FFN + LayerNorm tail forward (8 waves x 16 rows) and the fused backward dX pass
+    elif dispatch == "small_fused":  # D = 384: the whole-block forward kernel (8 waves x 16 rows) and the fused backward dX pass
         summ = prof.summary()
-        assert sum(v["launches"] for k, v in summ.items() if k[0] == "ffn_ln_fwd") == 36   # student, teacher, local passes
+        assert sum(v["launches"] for k, v in summ.items() if k[0] == "proj_ffn_ln_fwd") == 36   # student, teacher, local passes
+        assert not [k for k in summ if k[0] == "ffn_ln_fwd"]
+        # the next block's QKV rides in the kernel: one stand-alone in_proj GEMM per pass (block 0), no stand-alone out-proj
+        assert sum(v["launches"] for k, v in summ.items() if k[0] == "gemm_nt" and k[2] == 3 * D and k[3] == D) == 3
+        assert not [k for k in summ if k[0] == "gemm_nt" and k[2] == D and k[3] == D and k[4] == ops.EPI_RESID]
         assert sum(v["launches"] for k, v in summ.items() if k[0] == "ffn_bwd_dx") == 12
         assert not [k for k in summ if k[0] == "gemm_nt" and k[2] == 2048 and k[3] == D and k[4] == ops.EPI_RELU]  # no stand-alone linear1
     # ---- loss
