@@ -64,6 +64,8 @@ def parse():
     ap.add_argument("--no-launch-profile", action="store_true")
     ap.add_argument("--verify-equal-batch", action="store_true", help="N > 1 self-check before the timed region: loss and "
                     "gradient norm of the N-rank data-parallel step vs the same GLOBAL batch run by one rank alone (rel <= 3e-2)")
+    ap.add_argument("--overlap", action="store_true", help="force the teacher / local-crop / dW side streams on (default: on for "
+                    "D >= 768 only, see ChAdaViT.dw_side_stream)")
     ap.add_argument("--serial", action="store_true", help="one HIP stream (no teacher/local/dW side streams): per-kernel "
                     "durations in a rocprofv3 trace are then stand-alone durations (profiles/README.md)")
     return ap.parse_args()
@@ -444,6 +446,9 @@ def main():
     if args.serial:
         model.overlap_streams = False
         model.backbone.dw_side_stream = False
+    if args.overlap:
+        model.overlap_streams = True
+        model.backbone.dw_side_stream = True
 
     # ---- synthetic batch, resident in HBM (randn crops, A1 collate layout)
     # Mixed-channel workloads: ONE global batch of B * world images (same seed on every rank) is split with the token-balanced
@@ -601,7 +606,7 @@ def main():
             except OSError:
                 pass
             roof.update({"kernel": "/".join(str(k) for k in key), "avg_us": round(st["avg_us"], 2),
-                         "avg_us_in_step": round(st.get("in_step_avg_us", float("nan")), 2), "streams": "serial" if args.serial else "overlapped",
+                         "avg_us_in_step": round(st.get("in_step_avg_us", float("nan")), 2), "streams": "overlapped" if model.backbone.dw_side_stream else "serial",
                          "launches_per_step": st["launches"],
                          "share_of_instrumented_gpu_time": round(st["total_ms"] / tot_ms, 4),
                          "instrumented_ms_per_step": round(tot_ms, 3)})

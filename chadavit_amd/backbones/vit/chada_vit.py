@@ -100,7 +100,11 @@ class ChAdaViT(nn.Module):
         self._tn_ws: Optional[torch.Tensor] = None
         self._ln_ws: Optional[torch.Tensor] = None
         self.grad_ready_hook = None  # callable(flat, begin, end) fired as each slab of gradients completes
-        self.dw_side_stream = True   # weight-gradient GEMMs on a second HIP stream beside the dX chain
+        # weight-gradient GEMMs on a second HIP stream beside the dX chain.  Default by measurement (round 2, same box, img/s
+        # overlapped vs one stream): Base 150.4 vs 145.4 -- its GEMM-chain kernels leave grid tails the side stream fills;
+        # Tiny 4469 vs 4540, Small 1087 vs 1084, the 4-image reference config 386 vs 428 -- the fused block kernels fill the
+        # chip by themselves (2 resident blocks per CU) and a concurrent kernel only splits L2 / CU slots and adds fork-join edges
+        self.dw_side_stream = embed_dim >= 768
         self.fused_ffn = True        # linear1 -> relu -> linear2 (+ residual) in one kernel where the shape allows (D = 192)
         # token rows from which a block runs as the whole-block kernel (out-proj .. next QKV in one launch) instead of the
         # GEMM + LayerNorm chain; 0 forces the fused path at any size (the parity tests do, so that the benchmarked dispatch

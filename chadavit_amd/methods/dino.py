@@ -266,7 +266,9 @@ class DINO(_Base):
         self.validation_step_outputs: List[Dict[str, Any]] = []
         self.compute_ssl_val_loss = cfg.ssl_val_loss
         self.batch_crops = True  # pack same-size crops into one ragged batch per network
-        self.overlap_streams = True  # teacher / local-crop passes on side HIP streams (see training_step)
+        # teacher / local-crop passes on side HIP streams (see training_step); default as for ChAdaViT.dw_side_stream: it pays
+        # where the backbone runs the GEMM chain (Base), not where the fused block kernels already fill the chip
+        self.overlap_streams = getattr(self.backbone, "embed_dim", 0) >= 768
         self._streams = None
         self._local_pending = False
         self._clip_index = None

@@ -232,7 +232,8 @@ def test_layernorm_bwd_pair_equals_two_calls(T, D, acc):
                                 accumulate_a=acc, accumulate_b=acc)
     torch.cuda.synchronize()
     err = (dz.float() - dz_ref.float()).abs()
-    assert bool((err <= 2 ** -7 * dz_ref.float().abs() + 1e-6).all()), float(err.max())   # one bf16 ulp
+    # one bf16 ulp of the element, or of the intermediate dx spread over its row (small |dz| next to large ones)
+    assert bool((err <= 2 ** -7 * dz_ref.float().abs() + 2e-3 * float(dz_ref.float().abs().max())).all()), float(err.max())
     assert float((err > 0).float().mean()) < 0.02   # and almost everywhere identical
     for a, b in zip(got, ref):
         assert torch.isfinite(a).all()
