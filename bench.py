@@ -603,6 +603,10 @@ def main():
                     pmc = json.load(f).get("/".join(str(k) for k in key))
                 if pmc:
                     roof["traffic"] = pmc["traffic_bytes"]
+                    if roof["bound"] == "mfma":  # the same launch against the OTHER roof: measured HBM bytes over its duration
+                        gbs = pmc["traffic_bytes"] / (st["avg_us"] * 1e-6) / 1e9
+                        roof["hbm_gbs"] = round(gbs, 1)
+                        roof["hbm_frac"] = round(gbs / PEAK_HBM_GBS, 4)
             except OSError:
                 pass
             roof.update({"kernel": "/".join(str(k) for k in key), "avg_us": round(st["avg_us"], 2),
