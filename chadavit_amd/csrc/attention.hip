@@ -232,7 +232,10 @@ struct FwdDmaCfg {
   // dh = 192 block keeps 2 stages in 48 KiB and fits 256 VGPRs: 2 blocks per CU instead of one with 96 KiB / 396 VGPRs
   static constexpr int KVT = (DH > 96) ? 32 : 64, KB = KVT / 16, K2 = KVT / 32;
   static constexpr int NKR = KB * KS, NVR = K2 * DB, NR = NKR + NVR;  // 1 KiB records per stage
-  static constexpr int NRW = (NR + 3) / 4;                           // LDS-DMA instructions per wave and tile
+  // waves per block: 4 x 32 (16 above dh = 96... see CB) query rows; dh = 384 (Base) runs EIGHT waves x 16 rows as the CU's only block:
+  // its 48 KiB stages (2 x 48 = 96 KiB) are then shared by 128 query rows instead of 64, two waves per SIMD
+  static constexpr int NW = (DH > 192) ? 8 : 4;
+  static constexpr int NRW = (NR + NW - 1) / NW;                     // LDS-DMA instructions per wave and tile
   static constexpr int STAGE = NR * 512;
 };
 
@@ -249,9 +252,9 @@ __device__ __forceinline__ void attn_fwd_tile(BufRsrc qb, bf16_t* __restrict__ d
   if (issue) {
 #pragma unroll
     for (int i = 0; i < NRW; ++i) {
-      if (NR % 4 != 0 && w + 4 * i >= NR) continue;  // wave-uniform: NR is not a multiple of 4 for dh = 16
+      if (NR % C::NW != 0 && w + C::NW * i >= NR) continue;  // wave-uniform: NR is not a multiple of the wave count for dh = 16
       const unsigned off = (unsigned)min((kt + 1) * KVT + rec_row[i], len - 1) * ldu + rec_col[i];
-      lds_dma16(qb, dst + (w + 4 * i) * 512, off * 2, 0);
+      lds_dma16(qb, dst + (w + C::NW * i) * 512, off * 2, 0);
     }
   }
   __builtin_amdgcn_sched_barrier(0);  // the DMA goes out FIRST: free of the alias edge, the scheduler would sink it below the math
@@ -353,24 +356,25 @@ __device__ __forceinline__ void attn_fwd_tile(BufRsrc qb, bf16_t* __restrict__ d
 // Same arithmetic (and bit-identical results) as attn_fwd_kernel.
 // =====================================================================================
 template <int DH, int CB>
-__global__ __launch_bounds__(256, (DH <= 192 ? 2 : 1)) void attn_fwd_dma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(64 * FwdDmaCfg<DH>::NW, (DH <= 192 ? 2 : 1)) void attn_fwd_dma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                            float* __restrict__ lse, const int* __restrict__ cu,
                                                            const int* __restrict__ work, int T, int D, int H, float scale) {
   // dh = 16 (12 heads at D = 192: the reference's default constructor, HOW_TO_USE.ipynb cell 13) runs as ONE 32-wide k-step
   // whose upper 16 slots are zero in the Q fragments; the K records then carry 16 columns of the neighbouring head (or of
   // the V section) in those slots -- finite values times zero.
   using C = FwdDmaCfg<DH>;
-  constexpr int KS = C::KS, DB = C::DB, KVT = C::KVT, NKR = C::NKR, NR = C::NR, NRW = C::NRW, STAGE = C::STAGE;
+  constexpr int KS = C::KS, DB = C::DB, KVT = C::KVT, NKR = C::NKR, NR = C::NR, NRW = C::NRW, STAGE = C::STAGE, NW = C::NW;
+  constexpr int QPB = NW * 16 * CB;  // query rows per block
   __shared__ __attribute__((aligned(16))) bf16_t smem[2 * STAGE];
 
   const int tid = threadIdx.x, l = tid & 63, g = l >> 4, li = l & 15;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  constexpr int SPLIT = 2 / CB;
+  constexpr int SPLIT = TILE / QPB;
   const WorkItem it = decode_work<SPLIT>(work, H);
   const int b = it.b, qt = it.t, h = it.h, part = it.part;
   if (b < 0) return;
   const int seq0 = cu[b], len = cu[b + 1] - seq0;
-  if (qt * TILE + part * 64 * CB >= len) return;
+  if (qt * TILE + part * QPB >= len) return;
   const size_t ld = 3 * (size_t)D;
   const bf16_t* qbase = qkv + (size_t)seq0 * ld + h * DH;
   const bf16_t* kbase = qbase + D;
@@ -381,7 +385,7 @@ __global__ __launch_bounds__(256, (DH <= 192 ? 2 : 1)) void attn_fwd_dma_kernel(
   int qrow[CB];
 #pragma unroll
   for (int cb = 0; cb < CB; ++cb) {
-    qrow[cb] = qt * TILE + part * 64 * CB + w * 16 * CB + cb * 16 + li;
+    qrow[cb] = qt * TILE + part * QPB + w * 16 * CB + cb * 16 + li;
     const int qr = min(qrow[cb], len - 1);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -409,7 +413,7 @@ __global__ __launch_bounds__(256, (DH <= 192 ? 2 : 1)) void attn_fwd_dma_kernel(
   unsigned rec_col[NRW];
 #pragma unroll
   for (int i = 0; i < NRW; ++i) {
-    const int r = w + 4 * i;
+    const int r = w + NW * i;
     if (r < NKR) {
       rec_row[i] = (r / KS) * 16 + li;
       rec_col[i] = D + (r % KS) * 32 + g * 8;
@@ -421,14 +425,14 @@ __global__ __launch_bounds__(256, (DH <= 192 ? 2 : 1)) void attn_fwd_dma_kernel(
   }
   const unsigned ldu = 3u * (unsigned)D;
   const int nkt = (len + KVT - 1) / KVT;
-  const int qrow0 = qt * TILE + part * 64 * CB + w * 16 * CB;  // first query row of this wave
+  const int qrow0 = qt * TILE + part * QPB + w * 16 * CB;  // first query row of this wave
   const BufRsrc qrs = make_rsrc(qbase);  // LDS-DMA through a buffer resource: see lds_dma16
   // tile 0: no LDS read follows before the first barrier, issued bare
 #pragma unroll
   for (int i = 0; i < NRW; ++i) {
-    if (NR % 4 != 0 && w + 4 * i >= NR) continue;  // wave-uniform: NR is not a multiple of 4 for dh = 16
+    if (NR % NW != 0 && w + NW * i >= NR) continue;  // wave-uniform: NR is not a multiple of the wave count for dh = 16
     const unsigned off = (unsigned)min(rec_row[i], len - 1) * ldu + rec_col[i];
-    lds_dma16(qrs, smem + (w + 4 * i) * 512, off * 2, 0);
+    lds_dma16(qrs, smem + (w + NW * i) * 512, off * 2, 0);
   }
   for (int kt = 0; kt < nkt - 1; ++kt) {
     // tile kt has landed (LDS-DMA completion is visible only through the issuing wave's vmcnt) and everybody is done
@@ -1367,7 +1371,13 @@ extern "C" int chadavit_attn_fwd(const chada_bf16* qkv_, chada_bf16* out_, float
     case 16:  // forward only (feature extraction with the 12-head default constructor); training uses the 2-head factory
       hipLaunchKernelGGL((attn_fwd_dma_kernel<16, 2>), dim3(n_work * H), blk, 0, s, qkv, out, lse, cu_seqlens, work, T, D, H, scale);
       break;
-    FWD_DMA_CASE(32, 2) FWD_DMA_CASE(64, 2) FWD_DMA_CASE(96, 2) FWD_DMA_CASE(192, 2) FWD_CASE(384, 1)
+    FWD_DMA_CASE(32, 2) FWD_DMA_CASE(64, 2) FWD_DMA_CASE(96, 2) FWD_DMA_CASE(192, 2)
+    case 384:  // eight waves x 16 query rows per 128-row tile (FwdDmaCfg<384>::NW)
+      if (use_dma)
+        hipLaunchKernelGGL((attn_fwd_dma_kernel<384, 1>), dim3(n_work * H), dim3(512), 0, s, qkv, out, lse, cu_seqlens, work, T, D, H, scale);
+      else
+        hipLaunchKernelGGL((attn_fwd_kernel<384, 1>), dim3(n_work * 2 * H), blk, 0, s, qkv, out, lse, cu_seqlens, work, T, D, H, scale);
+      break;
     default: return 2;
   }
 #undef FWD_CASE

@@ -313,10 +313,11 @@ def test_attention_fwd_bwd(nch, p, D, H):
     _close(dqkv[:, :D], g[:, :D], 3e-2, 3e-2 * scale, "dQ")
 
 
-@pytest.mark.parametrize("D", [192, 384])
+@pytest.mark.parametrize("D", [192, 384, 768])
 def test_attention_lengths_around_the_tile_boundaries(D):
     """Sequences of 2 .. 257 tokens straddling every 16 / 32 / 64 / 128-row boundary: the last tile of the LDS-DMA kernels
-    skips the 16-row blocks without a valid key / query and whole waves without a valid row (dh = 96 and 192)."""
+    skips the 16-row blocks without a valid key / query and whole waves without a valid row (dh = 96, 192 and -- forward: eight
+    waves x 16 query rows -- 384)."""
     from chadavit_amd import ops
     from chadavit_amd.ragged import RaggedBatch
     dev = _dev()
