@@ -383,7 +383,8 @@ def _block_bwd(m: ChAdaViT, flat: FlatParams, i: int, dx2, saved, rb: RaggedBatc
     if pend is not None:
         dh_n, x_n, mean_n, rstd_n, g1_n, gw_n, gb_n, dy_n = pend  # x_n is this block's output: LN2(z)
         dz = ops.layernorm_bwd_pair(dh_n, x_n, mean_n, rstd_n, g1_n, dy_n, z, st[4], st[5], flat.f(b + "norm2.weight"), gw_n, gb_n,
-                                    G(b + "norm2.weight"), G(b + "norm2.bias"), ln_ws, accumulate_a=True, accumulate_b=acc)
+                                    G(b + "norm2.weight"), G(b + "norm2.bias"), ln_ws, accumulate_a=True, accumulate_b=acc,
+                                    beta_b=flat.f(b + "norm2.bias"))  # x_n is rebuilt from z in the kernel, not read
     else:
         dz = ops.layernorm_bwd(dx2, z, st[4], st[5], flat.f(b + "norm2.weight"), G(b + "norm2.weight"), G(b + "norm2.bias"), ln_ws,
                                accumulate=acc)

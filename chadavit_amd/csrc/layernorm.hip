@@ -439,23 +439,26 @@ __global__ __launch_bounds__(256) void ln_bwd_quad_kernel(const bf16_t* __restri
 // dx is only ever consumed by the second pass: it stays in registers (rounded to bf16 as the two-launch chain would store it), which
 // takes one write and one read of a [T, D] tensor out of every block boundary of the backward.  Partials: [a: dgamma | dbeta] in
 // partial_a, [b: ...] in partial_b, same layout as ln_bwd_quad_kernel's.
-template <int QD>
+// RECOMPUTE_X: x is not read but rebuilt from z as the forward produced it, x = bf16(LN_b(z)) with the saved statistics (the same
+// expression, ln_apply, in every forward kernel): one stream of [T, D] less (5 -> 4).
+template <int QD, bool RECOMPUTE_X>
 __global__ __launch_bounds__(256) void ln_bwd_pair_quad_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                                const float* __restrict__ mean_a, const float* __restrict__ rstd_a,
                                                                const float* __restrict__ gamma_a, const bf16_t* __restrict__ dres,
                                                                const bf16_t* __restrict__ z, const float* __restrict__ mean_b,
                                                                const float* __restrict__ rstd_b, const float* __restrict__ gamma_b,
-                                                               bf16_t* __restrict__ dz, float* __restrict__ partial_a,
-                                                               float* __restrict__ partial_b, int T) {
+                                                               const float* __restrict__ beta_b, bf16_t* __restrict__ dz,
+                                                               float* __restrict__ partial_a, float* __restrict__ partial_b, int T) {
   using QR = QuadRow<QD>;
   __shared__ float red[4 * QR::RPW][2][QD];
   const QR q;
   const int w = threadIdx.x >> 6;
-  f32x4 ga[3], gb[3], dga[3], dba[3], dgb[3], dbb[3];
+  f32x4 ga[3], gb[3], bb[3], dga[3], dba[3], dgb[3], dbb[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     ga[j] = *reinterpret_cast<const f32x4*>(gamma_a + q.col(j));
     gb[j] = *reinterpret_cast<const f32x4*>(gamma_b + q.col(j));
+    if constexpr (RECOMPUTE_X) bb[j] = *reinterpret_cast<const f32x4*>(beta_b + q.col(j));
     dga[j] = dba[j] = dgb[j] = dbb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   constexpr float invD = 1.0f / QD;
@@ -468,9 +471,17 @@ __global__ __launch_bounds__(256) void ln_bwd_pair_quad_kernel(const bf16_t* __r
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      const f32x4 xv = ld4(x + (size_t)rr * QD + q.col(j));
       f32x4 dv = ld4(dy + (size_t)rr * QD + q.col(j));
-      zh[j] = (ld4(z + (size_t)rr * QD + q.col(j)) - mub) * rsb;
+      const f32x4 zv = ld4(z + (size_t)rr * QD + q.col(j));
+      zh[j] = (zv - mub) * rsb;
+      f32x4 xv;
+      if constexpr (RECOMPUTE_X) {
+        const f32x4 o = ln_apply(zv, mub, rsb, gb[j], bb[j]);
+        const bf16x4 ob = pack4(o[0], o[1], o[2], o[3]);
+        xv = f32x4{(float)ob[0], (float)ob[1], (float)ob[2], (float)ob[3]};
+      } else {
+        xv = ld4(x + (size_t)rr * QD + q.col(j));
+      }
       rv[j] = ld4(dres + (size_t)rr * QD + q.col(j));
       if (!live) { dv = f32x4{0.f, 0.f, 0.f, 0.f}; rv[j] = dv; }  // rows past T contribute nothing to either pair of column sums
       xh[j] = (xv - mua) * rsa;
@@ -631,11 +642,11 @@ extern "C" int chadavit_layernorm_bwd(const chada_bf16* dy, const chada_bf16* x,
 
 extern "C" int chadavit_layernorm_bwd_pair(const chada_bf16* dy, const chada_bf16* x, const float* mean_a, const float* rstd_a,
                                            const float* gamma_a, const chada_bf16* dres, const chada_bf16* z, const float* mean_b,
-                                           const float* rstd_b, const float* gamma_b, chada_bf16* dz, float* dgamma_a, float* dbeta_a,
-                                           int accumulate_a, float* dgamma_b, float* dbeta_b, int accumulate_b, int T, int D,
+                                           const float* rstd_b, const float* gamma_b, const float* beta_b, chada_bf16* dz, float* dgamma_a,
+                                           float* dbeta_a, int accumulate_a, float* dgamma_b, float* dbeta_b, int accumulate_b, int T, int D,
                                            float* workspace, void* stream) {
   CHADA_ENTRY();
-  if (!dy || !x || !mean_a || !rstd_a || !gamma_a || !dres || !z || !mean_b || !rstd_b || !gamma_b || !dz || !dgamma_a || !dbeta_a ||
+  if ((!x && !beta_b) || !dy || !mean_a || !rstd_a || !gamma_a || !dres || !z || !mean_b || !rstd_b || !gamma_b || !dz || !dgamma_a || !dbeta_a ||
       !dgamma_b || !dbeta_b || !workspace || T <= 0)
     return 1;
   if (D != 192 && D != 384 && D != 768) return 2;
@@ -645,11 +656,12 @@ extern "C" int chadavit_layernorm_bwd_pair(const chada_bf16* dy, const chada_bf1
   if (gq > LN_BWD_PARTIALS) gq = LN_BWD_PARTIALS;
   float* pa = workspace;
   float* pb = workspace + (size_t)LN_BWD_PARTIALS * 2 * D;
-#define LNPAIR(DV)                                                                                                                      \
-  hipLaunchKernelGGL(ln_bwd_pair_quad_kernel<DV>, dim3(gq), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(dy),                       \
+#define LNPAIR(DV, RX)                                                                                                                  \
+  hipLaunchKernelGGL((ln_bwd_pair_quad_kernel<DV, RX>), dim3(gq), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(dy),                 \
                      reinterpret_cast<const bf16_t*>(x), mean_a, rstd_a, gamma_a, reinterpret_cast<const bf16_t*>(dres),                \
-                     reinterpret_cast<const bf16_t*>(z), mean_b, rstd_b, gamma_b, reinterpret_cast<bf16_t*>(dz), pa, pb, T)
-  if (D == 192) LNPAIR(192); else if (D == 384) LNPAIR(384); else LNPAIR(768);
+                     reinterpret_cast<const bf16_t*>(z), mean_b, rstd_b, gamma_b, beta_b, reinterpret_cast<bf16_t*>(dz), pa, pb, T)
+  if (x) { if (D == 192) LNPAIR(192, false); else if (D == 384) LNPAIR(384, false); else LNPAIR(768, false); }
+  else { if (D == 192) LNPAIR(192, true); else if (D == 384) LNPAIR(384, true); else LNPAIR(768, true); }
 #undef LNPAIR
   CHADA_CHECK_LAUNCH();
   hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * D + 15) / 16), dim3(256), 0, s, pa, dgamma_a, dbeta_a, gq, D, accumulate_a);

@@ -391,10 +391,13 @@ LN_PAIR_WIDTHS = (192, 384, 768)
 
 @_timed(lambda dy, x, *a, **k: ("layernorm_bwd_pair", x.shape[0], x.shape[1]))
 def layernorm_bwd_pair(dy, x, mean_a, rstd_a, gamma_a, dres, z, mean_b, rstd_b, gamma_b, dgamma_a, dbeta_a, dgamma_b, dbeta_b, workspace,
-                       accumulate_a=False, accumulate_b=False, dz=None):
-    """dz = LN_b'(LN_a'(dy; x) + dres; z) in one sweep (the boundary between two blocks in the backward); returns dz."""
+                       accumulate_a=False, accumulate_b=False, dz=None, beta_b=None):
+    """dz = LN_b'(LN_a'(dy; x) + dres; z) in one sweep (the boundary between two blocks in the backward); returns dz.  With `beta_b`
+    the kernel rebuilds x = LN_b(z) itself instead of reading it (x is then only used for its shape)."""
     for t, n in ((dy, "dy"), (x, "x"), (dres, "dres"), (z, "z")):
         _req(t, BF16, n)
+    if beta_b is not None:
+        _req(beta_b, F32, "beta_b")
     for t, n in ((mean_a, "mean_a"), (rstd_a, "rstd_a"), (gamma_a, "gamma_a"), (mean_b, "mean_b"), (rstd_b, "rstd_b"), (gamma_b, "gamma_b"),
                  (dgamma_a, "dgamma_a"), (dbeta_a, "dbeta_a"), (dgamma_b, "dgamma_b"), (dbeta_b, "dbeta_b"), (workspace, "workspace")):
         _req(t, F32, n)
@@ -403,8 +406,9 @@ def layernorm_bwd_pair(dy, x, mean_a, rstd_a, gamma_a, dres, z, mean_b, rstd_b, 
         raise RuntimeError("layernorm_bwd_pair: workspace too small (ops.layernorm_bwd_workspace)")
     if dz is None:
         dz = torch.empty_like(z)
-    rc = lib().chadavit_layernorm_bwd_pair(_ptr(dy), _ptr(x), _ptr(mean_a), _ptr(rstd_a), _ptr(gamma_a), _ptr(dres), _ptr(z), _ptr(mean_b),
-                                           _ptr(rstd_b), _ptr(gamma_b), _ptr(dz), _ptr(dgamma_a), _ptr(dbeta_a), c_int(1 if accumulate_a else 0),
+    rc = lib().chadavit_layernorm_bwd_pair(_ptr(dy), _ptr(x if beta_b is None else None), _ptr(mean_a), _ptr(rstd_a), _ptr(gamma_a), _ptr(dres), _ptr(z),
+                                           _ptr(mean_b), _ptr(rstd_b), _ptr(gamma_b), _ptr(beta_b), _ptr(dz), _ptr(dgamma_a), _ptr(dbeta_a),
+                                           c_int(1 if accumulate_a else 0),
                                            _ptr(dgamma_b), _ptr(dbeta_b), c_int(1 if accumulate_b else 0), c_int(T), c_int(D), _ptr(workspace),
                                            _stream())
     _chk(rc, "chadavit_layernorm_bwd_pair")

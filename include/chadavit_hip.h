@@ -97,14 +97,15 @@ int chadavit_layernorm_bwd(const chada_bf16* dy, const chada_bf16* x, const floa
 int chadavit_layernorm_bwd_partials(void); /* number of partial rows the bwd workspace must hold */
 /* Two chained LayerNorm backward passes in one sweep -- the boundary between two post-norm blocks in the backward (autograd of
  * chada_vit.py:96 of layer i and :100 of layer i-1):   dx = LN_a'(dy; x) + dres   then   dz = LN_b'(dx; z)
- * where x = LN_b(z) is layer i's input.  dx is not written (it is rounded to bf16 in registers, as the two-call chain would store
+ * where x = LN_b(z) is layer i's input -- x may be NULL when beta_b is given: it is then rebuilt from z exactly as the forward kernels
+ * produce it (one [T, D] read less).  dx is not written (it is rounded to bf16 in registers, as the two-call chain would store
  * it).  (dgamma, dbeta) of both norms are produced (accumulate_* != 0: added).  D in {192, 384, 768} (rc 2 otherwise);
  * workspace >= 2 * chadavit_layernorm_bwd_partials() * 2 * D floats. */
 int chadavit_layernorm_bwd_pair(const chada_bf16* dy, const chada_bf16* x, const float* mean_a, const float* rstd_a,
                                 const float* gamma_a, const chada_bf16* dres, const chada_bf16* z, const float* mean_b,
-                                const float* rstd_b, const float* gamma_b, chada_bf16* dz, float* dgamma_a, float* dbeta_a,
-                                int accumulate_a, float* dgamma_b, float* dbeta_b, int accumulate_b, int T, int D, float* workspace,
-                                void* stream);
+                                const float* rstd_b, const float* gamma_b, const float* beta_b, chada_bf16* dz, float* dgamma_a,
+                                float* dbeta_a, int accumulate_a, float* dgamma_b, float* dbeta_b, int accumulate_b, int T, int D,
+                                float* workspace, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Variable-length multi-head self-attention over packed sequences (flash style, never materialises

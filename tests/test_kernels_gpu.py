@@ -230,7 +230,12 @@ def test_layernorm_bwd_pair_equals_two_calls(T, D, acc):
     got = [torch.full((D,), init, device=dev) for _ in range(4)]
     dz = ops.layernorm_bwd_pair(dy, x, st[0], st[1], ga, dres, z, st[2], st[3], gb, got[0], got[1], got[2], got[3], ws,
                                 accumulate_a=acc, accumulate_b=acc)
+    # the instance that rebuilds x from z instead of reading it: x = bf16(LN_b(z)) is reproduced bit for bit, so is everything else
+    got2 = [torch.full((D,), init, device=dev) for _ in range(4)]
+    dz2 = ops.layernorm_bwd_pair(dy, x, st[0], st[1], ga, dres, z, st[2], st[3], gb, got2[0], got2[1], got2[2], got2[3], ws,
+                                 accumulate_a=acc, accumulate_b=acc, beta_b=bb)
     torch.cuda.synchronize()
+    assert torch.equal(dz2, dz) and all(torch.equal(a, b) for a, b in zip(got2, got))
     err = (dz.float() - dz_ref.float()).abs()
     # one bf16 ulp of the element, or of the intermediate dx spread over its row (small |dz| next to large ones)
     assert bool((err <= 2 ** -7 * dz_ref.float().abs() + 2e-3 * float(dz_ref.float().abs().max())).all()), float(err.max())
