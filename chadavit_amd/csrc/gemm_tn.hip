@@ -280,6 +280,10 @@ extern "C" int chadavit_gemm_tn(const chada_bf16* A_, int lda, const chada_bf16*
   int bi = 0, bj = 0;
   for (auto& c : cfgs)
     if (I % c[0] == 0 && J % c[1] == 0) { bi = c[0]; bj = c[1]; break; }
+  // dW_qkv at D = 192 (576 x 192): three 192 x 192 tiles instead of nine 64 x 192 ones -- the shared operand h is pulled through LDS
+  // three times instead of nine
+  static const bool big = getenv("CHADA_TN_NO192") == nullptr;
+  if (big && bi == 64 && bj == 192 && I % 192 == 0 && I >= 384) bi = 192;
   const int tiles = (I / bi) * (J / bj);
   int splits = (512 + tiles - 1) / tiles;  // two resident blocks per CU, one wave of blocks: more (or fewer) measured slower
   const int max_by_t = (T + 255) / 256;  // at least 256 rows per split
@@ -295,7 +299,7 @@ extern "C" int chadavit_gemm_tn(const chada_bf16* A_, int lda, const chada_bf16*
 #define TN_CASE(a, b) \
   if (bi == a && bj == b) launch_tn<a, b>(A, lda, B, ldb, part, part_cs, T, I, J, tchunk, splits, s);
   TN_CASE(128, 192) TN_CASE(192, 128) TN_CASE(128, 128) TN_CASE(64, 192) TN_CASE(192, 64) TN_CASE(128, 64)
-  TN_CASE(64, 128) TN_CASE(64, 64)
+  TN_CASE(64, 128) TN_CASE(64, 64) TN_CASE(192, 192)
 #undef TN_CASE
   CHADA_CHECK_LAUNCH();
   const size_t n4 = (size_t)I * J / 4;
