@@ -294,7 +294,10 @@ def _attn_ref(qkv, cu, H):
 
 @pytest.mark.parametrize("nch,p,D,H", [([3, 1, 10, 5], 196, 192, 2), ([1, 2], 36, 192, 2), ([2, 1, 1], 36, 384, 2),
                                        ([1], 4, 64, 2), ([3, 2], 36, 128, 2), ([1, 3], 196, 384, 2), ([2, 1], 36, 768, 2),
-                                       ([1, 2], 196, 768, 2), ([2, 3], 36, 192, 12), ([1, 2], 196, 192, 12)])
+                                       ([1, 2], 196, 768, 2), ([2, 3], 36, 192, 12), ([1, 2], 196, 192, 12),
+                                       # the longest sequence the model can see (10 channels x 196 patches + CLS = 1961 tokens: cfg5's
+                                       # "max-token stress"), at all three head widths
+                                       ([10, 1], 196, 192, 2), ([10], 196, 384, 2), ([1, 10], 196, 768, 2)])
 def test_attention_fwd_bwd(nch, p, D, H):
     from chadavit_amd import ops
     from chadavit_amd.ragged import RaggedBatch
