@@ -10,8 +10,8 @@ student fwd+bwd on the 2 global crops, teacher fwd on the 2 global crops, studen
 
 Workload (default) = BASELINE.json configs[1]: ChAda-ViT-Tiny/16 (D 192, depth 12, 2 heads, FFN 2048),
 fixed 3-channel 224x224 synthetic images, 2 global (224) + 8 local (96) crops, head 2048/256/4096,
-bf16 storage / fp32 accumulate, 256 images per GPU (31 GB of saved activations: sized for 288 GB HBM; 128/GPU runs ~6 %
-slower per image).  Inputs are resident in HBM before the timed region.
+bf16 storage / fp32 accumulate, 512 images per GPU (~60 GB of saved activations: sized for 288 GB HBM; 256/GPU -- the setting of
+round 1 and the first half of round 2 -- runs ~5 % slower per image, 128/GPU ~11 %; `--batch` selects).  Inputs are resident in HBM before the timed region.
 Prints ONE JSON line on rank 0 (contract in the task statement) including
   "roofline"     -- dominant kernel (largest share of GPU time among the instrumented entry points),
                     timed live with HIP events on the launch stream during the timed steps;
@@ -40,7 +40,8 @@ SUSTAINED_BF16_TFLOPS = 1750.0  # measured: what the MFMA pipes sustain on rando
 WORKLOADS = {
     # name: (embed_dim, channels spec, n_global, n_local, prototypes, per-GPU batch)
     "cfg2": dict(desc="ChAda-ViT-Tiny/16, fixed 3-channel 224x224, DINO 2 global + 8 local crops", D=192, channels="3",
-                 n_global=2, n_local=8, P=4096, batch=256),
+                 n_global=2, n_local=8, P=4096, batch=512),  # per-GPU images: 256 in rounds 1-2a; 512 uses ~50 of the 288 GB and amortises
+                 # the step's fixed ~5 ms (same box: 4521 / 4660 / 4743 images/s at 256 / 384 / 512; profiles/r02e_batch_sweep_cfg2.txt)
     "cfg1": dict(desc="ChAda-ViT-Tiny/16, 1-channel 224x224, DINO 2 global crops only", D=192, channels="1", n_global=2,
                  n_local=0, P=4096, batch=4),
     "cfg3": dict(desc="ChAda-ViT-Small/16, variable 1-10 channel, DINO 2 global + 8 local crops", D=384, channels="1-10",
