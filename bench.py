@@ -42,6 +42,9 @@ WORKLOADS = {
     "cfg2": dict(desc="ChAda-ViT-Tiny/16, fixed 3-channel 224x224, DINO 2 global + 8 local crops", D=192, channels="3",
                  n_global=2, n_local=8, P=4096, batch=512),  # per-GPU images: 256 in rounds 1-2a; 512 uses ~50 of the 288 GB and amortises
                  # the step's fixed ~5 ms (same box: 4521 / 4660 / 4743 images/s at 256 / 384 / 512; profiles/r02e_batch_sweep_cfg2.txt)
+    # the north star's wording of the target ("Tiny/16 ... 1-10-channel multi-crop batches"): configs[1] with the channel mix of configs[2]
+    "cfg2-mixed": dict(desc="ChAda-ViT-Tiny/16, variable 1-10 channel, DINO 2 global + 8 local crops", D=192, channels="1-10",
+                       n_global=2, n_local=8, P=4096, batch=256),
     "cfg1": dict(desc="ChAda-ViT-Tiny/16, 1-channel 224x224, DINO 2 global crops only", D=192, channels="1", n_global=2,
                  n_local=0, P=4096, batch=4),
     "cfg3": dict(desc="ChAda-ViT-Small/16, variable 1-10 channel, DINO 2 global + 8 local crops", D=384, channels="1-10",
