@@ -1290,19 +1290,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_dma_kernel(const bf16_t* _
 //   Kt records (db):        keys 0..31 x d = db*16 .. +15, 32-byte rows              (hardware transpose read)
 // 72 KiB per 32-key stage, two stages (one block per CU, two waves per SIMD).  Same arithmetic as attn_bwd_dq_kernel.
 // =====================================================================================
-template <int DH, bool MASKED>
+template <int DH, int CB, bool MASKED>
 __device__ __forceinline__ void attn_dq_fm_tile(BufRsrc qb, bf16_t* __restrict__ dst, const bf16_t* __restrict__ sK, bool issue, bool idle, int kt,
                                                 int len, unsigned ldu, float c, int w, int l, const int (&rec_row)[9], const unsigned (&rec_col)[9],
-                                                const bf16x8 (&qf)[DH / 32], const bf16x8 (&dof)[DH / 32], float L2, float dl,
-                                                f32x4 (&dq)[DH / 16]) {
-  constexpr int KS = DH / 32, DB = DH / 16, KVT = 32, NKR = 2 * KS;  // 24 K records, 24 V records, 24 Kt records
-  static_assert(3 * NKR == 72 && DB == NKR, "record bookkeeping below is for dh = 384");
+                                                const bf16x8 (&qf)[CB][DH / 32], const bf16x8 (&dof)[CB][DH / 32], const float (&L2)[CB],
+                                                const float (&dl)[CB], f32x4 (&dq)[CB][DH / 16]) {
+  constexpr int KS = DH / 32, DB = DH / 16, KVT = 32, NKR = 2 * KS, NW = DH / 48;  // NKR K records, NKR V records, DB (= NKR) Kt records
+  static_assert(6 * KS == 9 * NW && DB == NKR, "nine LDS-DMA instructions per wave and tile");
   const int g = l >> 4;
   if (issue) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
       const unsigned off = (unsigned)min((kt + 1) * KVT + rec_row[i], len - 1) * ldu + rec_col[i];
-      lds_dma16(qb, dst + (w + 8 * i) * 512, off * 2, 0);
+      lds_dma16(qb, dst + (w + NW * i) * 512, off * 2, 0);
     }
   }
   __builtin_amdgcn_sched_barrier(0);  // the DMA goes out FIRST
@@ -1310,7 +1310,7 @@ __device__ __forceinline__ void attn_dq_fm_tile(BufRsrc qb, bf16_t* __restrict__
   const bf16_t* sV = sK + NKR * 512;
   const bf16_t* sT = sK + 2 * NKR * 512;
   const int nvb = MASKED ? min(2, (len - kt * KVT + 15) >> 4) : 2;
-  f32x4 s[2], dp[2];
+  f32x4 s[CB][2], dp[CB][2];
   bf16x8 kf[2], vf[2];
   kf[0] = lds_read8(sK + l * 8);
   vf[0] = lds_read8(sV + l * 8);
@@ -1323,45 +1323,57 @@ __device__ __forceinline__ void attn_dq_fm_tile(BufRsrc qb, bf16_t* __restrict__
     }
     __builtin_amdgcn_sched_barrier(0);
     if (!MASKED || kb < nvb) {
-      s[kb] = (ks == 0) ? mfma16(kf[cur], qf[0], f32x4{0.f, 0.f, 0.f, 0.f}) : mfma16(kf[cur], qf[ks], s[kb]);
-      dp[kb] = (ks == 0) ? mfma16(vf[cur], dof[0], f32x4{0.f, 0.f, 0.f, 0.f}) : mfma16(vf[cur], dof[ks], dp[kb]);
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+        s[cb][kb] = (ks == 0) ? mfma16(kf[cur], qf[cb][0], f32x4{0.f, 0.f, 0.f, 0.f}) : mfma16(kf[cur], qf[cb][ks], s[cb][kb]);
+        dp[cb][kb] = (ks == 0) ? mfma16(vf[cur], dof[cb][0], f32x4{0.f, 0.f, 0.f, 0.f}) : mfma16(vf[cur], dof[cb][ks], dp[cb][kb]);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
   }
   bf16x8 tr[2];
   tr[0] = lds_read_tr8(sT, 16);
   __builtin_amdgcn_sched_barrier(0);
+  bf16x8 dsf[CB];
 #pragma unroll
-  for (int kb = 0; kb < 2; ++kb) {
-    if (MASKED && kb >= nvb) {
-      s[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
-      continue;
-    }
+  for (int cb = 0; cb < CB; ++cb) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float p = __builtin_amdgcn_exp2f(fmaf(s[kb][r], c, -L2));
-      if (MASKED && (kt * KVT + kb * 16 + 4 * g + r >= len)) p = 0.f;
-      s[kb][r] = p * (dp[kb][r] - dl);  // dS (unscaled)
+    for (int kb = 0; kb < 2; ++kb) {
+      if (MASKED && kb >= nvb) {
+        s[cb][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        continue;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float p = __builtin_amdgcn_exp2f(fmaf(s[cb][kb][r], c, -L2[cb]));
+        if (MASKED && (kt * KVT + kb * 16 + 4 * g + r >= len)) p = 0.f;
+        s[cb][kb][r] = p * (dp[cb][kb][r] - dl[cb]);  // dS (unscaled)
+      }
     }
+    dsf[cb] = pack8(s[cb][0], s[cb][1]);
   }
-  const bf16x8 dsf = pack8(s[0], s[1]);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int db = 0; db < DB; ++db) {
     if (db + 1 < DB) tr[(db + 1) & 1] = lds_read_tr8(sT + (db + 1) * 512, 16);
     __builtin_amdgcn_sched_barrier(0);
-    dq[db] = mfma16(tr[db & 1], dsf, dq[db]);
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) dq[cb][db] = mfma16(tr[db & 1], dsf[cb], dq[cb][db]);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
 
-template <int DH>
-__global__ __launch_bounds__(512, 1) void attn_bwd_dq_fm_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+// CB query blocks of 16 rows per wave, NW = DH / 48 waves: 8 x 16 rows at dh = 384 (the instance in use).  The dh = 192 instance
+// <192, 2> (4 waves x 32 rows, the same 192 registers of Q / dO / dQ state) was measured and is NOT dispatched: with two score
+// blocks per wave it spills 77 registers, 2089 us against 1182 us for the row-major kernel on cfg3's global pass.
+template <int DH, int CB>
+__global__ __launch_bounds__(64 * (DH / 48), (DH > 192 ? 1 : 2)) void attn_bwd_dq_fm_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                                 const float* __restrict__ lse, float* __restrict__ delta,
                                                                 bf16_t* __restrict__ dqkv, const int* __restrict__ cu,
                                                                 const int* __restrict__ work, int T, int D, int H, float scale,
                                                                 const bf16_t* __restrict__ out) {
-  constexpr int KS = DH / 32, DB = DH / 16, KVT = 32, NKR = 2 * KS, STAGE = 3 * NKR * 512;
+  constexpr int KS = DH / 32, DB = DH / 16, KVT = 32, NKR = 2 * KS, STAGE = 3 * NKR * 512, NW = DH / 48;
+  static_assert(NW * 16 * CB == TILE, "one block per 128-row work item");
   __shared__ __attribute__((aligned(16))) bf16_t smem[2 * STAGE];
   const int tid = threadIdx.x, l = tid & 63, g = l >> 4, li = l & 15;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1373,31 +1385,38 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dq_fm_kernel(const bf16_t* __
   const size_t ld = 3 * (size_t)D;
   const bf16_t* qbase = qkv + (size_t)seq0 * ld + h * DH;
   const float c = scale * LOG2E;
-  const int qrow = qt * TILE + w * 16 + li;
-  const int qr = min(qrow, len - 1);
-  bf16x8 qf[KS], dof[KS];
-  float part = 0.f;
+  bf16x8 qf[CB][KS], dof[CB][KS];
+  float L2[CB], dl[CB];
+  int qrow[CB];
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    qf[ks] = *reinterpret_cast<const bf16x8*>(qbase + (size_t)qr * ld + ks * 32 + g * 8);
-    dof[ks] = *reinterpret_cast<const bf16x8*>(dout + (size_t)(seq0 + qr) * D + h * DH + ks * 32 + g * 8);
-    const bf16x8 of = *reinterpret_cast<const bf16x8*>(out + (size_t)(seq0 + qr) * D + h * DH + ks * 32 + g * 8);
+  for (int cb = 0; cb < CB; ++cb) {
+    qrow[cb] = qt * TILE + w * 16 * CB + cb * 16 + li;
+    const int qr = min(qrow[cb], len - 1);
+    float part = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) part = fmaf((float)dof[ks][e], (float)of[e], part);
+    for (int ks = 0; ks < KS; ++ks) {
+      qf[cb][ks] = *reinterpret_cast<const bf16x8*>(qbase + (size_t)qr * ld + ks * 32 + g * 8);
+      dof[cb][ks] = *reinterpret_cast<const bf16x8*>(dout + (size_t)(seq0 + qr) * D + h * DH + ks * 32 + g * 8);
+      const bf16x8 of = *reinterpret_cast<const bf16x8*>(out + (size_t)(seq0 + qr) * D + h * DH + ks * 32 + g * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) part = fmaf((float)dof[cb][ks][e], (float)of[e], part);
+    }
+    L2[cb] = lse[(size_t)h * T + seq0 + qr] * LOG2E;
+    dl[cb] = rows_sum(part);  // delta = rowsum(dO * O), produced here for the dK/dV kernel as well
+    if (g == 0 && qrow[cb] < len) delta[(size_t)h * T + seq0 + qrow[cb]] = dl[cb];
   }
-  const float L2 = lse[(size_t)h * T + seq0 + qr] * LOG2E;
-  const float dl = rows_sum(part);  // delta = rowsum(dO * O), produced here for the dK/dV kernel as well
-  if (g == 0 && qrow < len) delta[(size_t)h * T + seq0 + qrow] = dl;
-  f32x4 dq[DB];
+  f32x4 dq[CB][DB];
 #pragma unroll
-  for (int db = 0; db < DB; ++db) dq[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+    for (int db = 0; db < DB; ++db) dq[cb][db] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // record r of a tile is fetched by wave r & 7 (instruction r >> 3): 0..23 K fragments, 24..47 V fragments, 48..71 K key-major
+  // record r of a tile is fetched by wave r % NW (instruction r / NW): NKR K fragments, NKR V fragments, DB K key-major
   int rec_row[9];
   unsigned rec_col[9];
 #pragma unroll
   for (int i = 0; i < 9; ++i) {
-    const int r = w + 8 * i;
+    const int r = w + NW * i;
     if (r < 2 * NKR) {
       const int rr = r % NKR;
       rec_row[i] = (rr / KS) * 16 + li;
@@ -1410,27 +1429,30 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dq_fm_kernel(const bf16_t* __
   }
   const unsigned ldu = 3u * (unsigned)D;
   const int nkt = (len + KVT - 1) / KVT;
-  const bool idle = qt * TILE + w * 16 >= len;
+  const bool idle = qt * TILE + w * 16 * CB >= len;
   const BufRsrc qrs = make_rsrc(qbase);
 #pragma unroll
   for (int i = 0; i < 9; ++i) {
     const unsigned off = (unsigned)min(rec_row[i], len - 1) * ldu + rec_col[i];
-    lds_dma16(qrs, smem + (w + 8 * i) * 512, off * 2, 0);
+    lds_dma16(qrs, smem + (w + NW * i) * 512, off * 2, 0);
   }
   for (int kt = 0; kt < nkt - 1; ++kt) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    attn_dq_fm_tile<DH, false>(qrs, smem + ((kt + 1) & 1) * STAGE, smem + (kt & 1) * STAGE, true, idle, kt, len, ldu, c, w, l, rec_row, rec_col, qf,
-                               dof, L2, dl, dq);
+    attn_dq_fm_tile<DH, CB, false>(qrs, smem + ((kt + 1) & 1) * STAGE, smem + (kt & 1) * STAGE, true, idle, kt, len, ldu, c, w, l, rec_row, rec_col,
+                                   qf, dof, L2, dl, dq);
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  attn_dq_fm_tile<DH, true>(qrs, smem + (nkt & 1) * STAGE, smem + ((nkt - 1) & 1) * STAGE, false, idle, nkt - 1, len, ldu, c, w, l, rec_row, rec_col,
-                            qf, dof, L2, dl, dq);
-  if (qrow < len) {
-    bf16_t* drow = dqkv + (size_t)(seq0 + qrow) * ld + h * DH + 4 * g;
+  attn_dq_fm_tile<DH, CB, true>(qrs, smem + (nkt & 1) * STAGE, smem + ((nkt - 1) & 1) * STAGE, false, idle, nkt - 1, len, ldu, c, w, l, rec_row,
+                                rec_col, qf, dof, L2, dl, dq);
 #pragma unroll
-    for (int db = 0; db < DB; ++db) {
-      const f32x4 v = dq[db] * scale;
-      *reinterpret_cast<bf16x4*>(drow + db * 16) = pack4(v[0], v[1], v[2], v[3]);
+  for (int cb = 0; cb < CB; ++cb) {
+    if (qrow[cb] < len) {
+      bf16_t* drow = dqkv + (size_t)(seq0 + qrow[cb]) * ld + h * DH + 4 * g;
+#pragma unroll
+      for (int db = 0; db < DB; ++db) {
+        const f32x4 v = dq[cb][db] * scale;
+        *reinterpret_cast<bf16x4*>(drow + db * 16) = pack4(v[0], v[1], v[2], v[3]);
+      }
     }
   }
 }
@@ -1572,7 +1594,7 @@ static int attn_bwd_launch(const chada_bf16* qkv_, const chada_bf16* out_, const
     else if ((parts & 2) && fuse_delta && use_dma && DHV == 192) /* one query block per wave: with two, Q + dO + dQ spill (65-124 VGPRs) */ \
       hipLaunchKernelGGL((attn_bwd_dq_dma_kernel<(DHV == 192 ? 192 : 96), 1, true>), dim3(n_work * 2 * H), blk, 0, s, qkv, dout, lse, delta, dqkv, cu_seqlens, work, T, D, H, scale, out); \
     else if ((parts & 2) && fuse_delta && use_dma && DHV == 384) /* eight waves x 16 query rows, fragment-major K / V / K^T stages */ \
-      hipLaunchKernelGGL((attn_bwd_dq_fm_kernel<384>), dim3(n_work * H), dim3(512), 0, s, qkv, dout, lse, delta, dqkv, cu_seqlens, work, T, D, H, scale, out); \
+      hipLaunchKernelGGL((attn_bwd_dq_fm_kernel<384, 1>), dim3(n_work * H), dim3(512), 0, s, qkv, dout, lse, delta, dqkv, cu_seqlens, work, T, D, H, scale, out); \
     else if ((parts & 2) && fuse_delta)                                                                           \
       hipLaunchKernelGGL((attn_bwd_dq_kernel<DHV, CBV, true>), dim3(n_work * (2 / CBV) * H), blk, 0, s, qkv, dout, lse, delta, dqkv, cu_seqlens, work, T, D, H, scale, out); \
     else if (parts & 2)                                                                                           \
