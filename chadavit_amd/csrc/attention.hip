@@ -847,9 +847,12 @@ __global__ __launch_bounds__(256, (DH <= 192 ? 2 : 1)) void attn_bwd_dkv_kernel(
 // force over all (k-step, block) positions); a first version derived for 16 consecutive lanes ran with 40 % conflict cycles.
 //   dh =  96 (192-byte rows, 12 chunks): low two chunk bits ^= (4 - (row >> 2)) & 3
 //   dh = 192 (384-byte rows, 24 chunks): chunk bits 1..2 ^= row bits 1..2
+//   dh = 384 (768-byte rows, 48 chunks: every row starts on bank 0): low four chunk bits ^= 2 (row & 7) ^ 9 (row >> 3 & 1) -- one of
+//            the 5376 GF(2)-linear maps of the row's low four bits that are conflict-free for both read kinds (brute force)
 template <int DH>
 __device__ __forceinline__ int dkv_swz(int row) {
-  if constexpr (DH == 192) return row & 6;
+  if constexpr (DH == 384) return (((row & 7) << 1) ^ (((row >> 3) & 1) * 9));
+  else if constexpr (DH == 192) return row & 6;
   else return (4 - ((row >> 2) & 3)) & 3;
 }
 
@@ -978,7 +981,7 @@ __device__ __forceinline__ void attn_dkv_tile(BufRsrc qg, BufRsrc dog, BufRsrc l
 }
 
 template <int DH, int CBK>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_dma_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+__global__ __launch_bounds__(256, (DH > 192 ? 1 : 2)) void attn_bwd_dkv_dma_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                               const float* __restrict__ lse, const float* __restrict__ delta,
                                                               bf16_t* __restrict__ dqkv, const int* __restrict__ cu,
                                                               const int* __restrict__ work, int T, int D, int H, float scale) {
@@ -1599,7 +1602,9 @@ static int attn_bwd_launch(const chada_bf16* qkv_, const chada_bf16* out_, const
       hipLaunchKernelGGL((attn_bwd_dq_kernel<DHV, CBV, true>), dim3(n_work * (2 / CBV) * H), blk, 0, s, qkv, dout, lse, delta, dqkv, cu_seqlens, work, T, D, H, scale, out); \
     else if (parts & 2)                                                                                           \
       hipLaunchKernelGGL((attn_bwd_dq_kernel<DHV, CBV, false>), dim3(n_work * (2 / CBV) * H), blk, 0, s, qkv, dout, lse, delta, dqkv, cu_seqlens, work, T, D, H, scale, out); \
-    if ((parts & 4) && use_dma && (DHV == 96 || DHV == 192))                                                      \
+    if ((parts & 4) && use_dma && DHV == 384) /* one wave per SIMD (288 registers of K / V / dK / dV state), 49 KiB row-major stages */ \
+      hipLaunchKernelGGL((attn_bwd_dkv_dma_kernel<(DHV == 384 ? 384 : 96), (DHV == 384 ? 1 : 2)>), dim3((DHV == 384 ? 2 : 1) * n_work * H), blk, 0, s, qkv, dout, lse, delta, dqkv, cu_seqlens, work, T, D, H, scale); \
+    else if ((parts & 4) && use_dma && (DHV == 96 || DHV == 192))                                                 \
       hipLaunchKernelGGL((attn_bwd_dkv_dma_kernel<(DHV == 192 ? 192 : 96), (DHV == 192 ? 1 : 2)>), dim3((DHV == 192 ? 2 : 1) * n_work * H), blk, 0, s, qkv, dout, lse, delta, dqkv, cu_seqlens, work, T, D, H, scale); \
     else if (parts & 4)                                                                                           \
       hipLaunchKernelGGL((attn_bwd_dkv_kernel<DHV, (DHV <= 96 ? 2 : 1)>), dim3((DHV <= 96 ? 1 : 2) * n_work * H), blk, 0, s, qkv, dout, lse, delta, dqkv, cu_seqlens, work, T, D, H, scale); \
