@@ -1367,10 +1367,11 @@ __device__ __forceinline__ void attn_dq_fm_tile(BufRsrc qb, bf16_t* __restrict__
 }
 
 // CB query blocks of 16 rows per wave, NW = DH / 48 waves: 8 x 16 rows at dh = 384 (the instance in use).  The dh = 192 instance
-// <192, 2> (4 waves x 32 rows, the same 192 registers of Q / dO / dQ state) was measured and is NOT dispatched: with two score
-// blocks per wave it spills 77 registers, 2089 us against 1182 us for the row-major kernel on cfg3's global pass.
+// <192, 2> (4 waves x 32 rows, the same 192 registers of Q / dO / dQ state) was measured and is NOT dispatched: at two waves per SIMD
+// it spills 77 registers (2089 us on cfg3's global pass), at one wave per SIMD (168 VGPRs + 122 AGPRs, no spill) it takes 1320 us --
+// against 1180 us for the row-major <192, 1> kernel.
 template <int DH, int CB>
-__global__ __launch_bounds__(64 * (DH / 48), (DH > 192 ? 1 : 2)) void attn_bwd_dq_fm_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+__global__ __launch_bounds__(64 * (DH / 48), 1) void attn_bwd_dq_fm_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                                 const float* __restrict__ lse, float* __restrict__ delta,
                                                                 bf16_t* __restrict__ dqkv, const int* __restrict__ cu,
                                                                 const int* __restrict__ work, int T, int D, int H, float scale,
