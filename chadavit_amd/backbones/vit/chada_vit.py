@@ -277,14 +277,16 @@ def _tokenize(m: ChAdaViT, flat: FlatParams, x, rb: RaggedBatch, pos_patch, add_
     return tokens, xs
 
 
-def _linear(m: ChAdaViT, flat: FlatParams, xb, wname: str, bias, epilogue=ops.EPI_NONE, aux=None):
-    """epilogue(xb W^T + bias): bf16 MFMA GEMM, or -- weight_dtype "fp8" -- OCP-MX fp8 operands on the scaled MFMA."""
+def _linear(m: ChAdaViT, flat: FlatParams, xb, wname: str, bias, epilogue=ops.EPI_NONE, aux=None, xq=None, emit_q=False, want_out=True):
+    """epilogue(xb W^T + bias): bf16 MFMA GEMM, or -- weight_dtype "fp8" -- OCP-MX fp8 operands on the scaled MFMA.
+    fp8 only: `xq` = (bytes, scales) of xb when a producing epilogue already quantised it; `emit_q` returns (out, (bytes, scales)) with
+    the result quantised by THIS GEMM's epilogue for the next one (out is None when want_out is False)."""
     if m.weight_dtype == "fp8":
         n, k = flat.shapes[wname]
         if n % 128 == 0 and k % 128 == 0 and epilogue in (ops.EPI_NONE, ops.EPI_RELU, ops.EPI_RESID):
             wq, ws = flat.mx8(wname)
-            xq, xs = ops.mx8_quantize(xb)
-            return ops.gemm_nt_mx8(xq, xs, wq, ws, bias=bias, epilogue=epilogue, aux=aux)
+            xq, xs = xq if xq is not None else ops.mx8_quantize(xb)
+            return ops.gemm_nt_mx8(xq, xs, wq, ws, bias=bias, epilogue=epilogue, aux=aux, emit_q=emit_q, want_out=want_out)
         raise RuntimeError(f"weight_dtype='fp8': {wname} {n}x{k} is not a multiple of 128 (embed_dim must be)")
     return ops.gemm_nt(xb, flat.w(wname), bias=bias, epilogue=epilogue, aux=aux)
 
@@ -344,8 +346,14 @@ def _block_fwd(m: ChAdaViT, flat: FlatParams, i: int, x, rb: RaggedBatch, save: 
                                     ln_b=None if last else ln1n, stats_a=(st[4], st[5]) if save else None,
                                     stats_b=(st_next[0], st_next[1]) if (save and not last) else None, relu_bits=rbits)
     else:
-        hid = _linear(m, flat, x1, b + "linear1.weight", flat.f(b + "linear1.bias"), ops.EPI_RELU)
-        z = _linear(m, flat, hid, b + "linear2.weight", flat.f(b + "linear2.bias"), ops.EPI_RESID, x1)
+        if m.weight_dtype == "fp8":
+            # linear1's epilogue hands linear2 its fp8 operand (no quantise pass over the hidden activation); the bf16 copy is written
+            # only when the backward needs it
+            hid, hq = _linear(m, flat, x1, b + "linear1.weight", flat.f(b + "linear1.bias"), ops.EPI_RELU, emit_q=True, want_out=save)
+            z = _linear(m, flat, hid, b + "linear2.weight", flat.f(b + "linear2.bias"), ops.EPI_RESID, x1, xq=hq)
+        else:
+            hid = _linear(m, flat, x1, b + "linear1.weight", flat.f(b + "linear1.bias"), ops.EPI_RELU)
+            z = _linear(m, flat, hid, b + "linear2.weight", flat.f(b + "linear2.bias"), ops.EPI_RESID, x1)
         if not last:
             x2, h_next = ops.layernorm_fwd2(z, ln2[0], ln2[1], ln1n[0], ln1n[1], ln2[2], ln1n[2],
                                             stats1=(st[4], st[5]) if save else None, stats2=(st_next[0], st_next[1]) if save else None)

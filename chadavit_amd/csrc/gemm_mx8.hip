@@ -42,6 +42,9 @@ struct Mx8Args {
   const uint8_t* Wq; const uint8_t* ws;   // [N, K] fp8, [K/32, lds_w] e8m0
   bf16_t* Out; const float* bias; const bf16_t* aux;
   int M, N, K, ldo, ldaux, lds_x, lds_w;
+  // optional second output: the result quantised again (e4m3 [M, N] + e8m0 [N/32, lds_o]) as the NEXT GEMM's X operand -- the same values
+  // chadavit_mx8_quantize would produce from Out, without the pass over it; Out itself may then be NULL (no-grad passes)
+  uint8_t* OutQ; uint8_t* outs; int lds_o;
 };
 
 __device__ __forceinline__ int mx_xcd_remap(int bid, int nblk) {
@@ -168,15 +171,22 @@ __global__ __launch_bounds__(512, 2) void gemm_mx8_kernel(Mx8Args a) {
   issue_next(smem);
   if (Q > 1) issue_next(smem + MX_STAGE);
   int st_rd = 0, st_wr = 2, ckt = 0, ctile = 0;
+  const int n_epi_stores = 8 * ((a.Out ? 1 : 0) + (a.OutQ ? 2 : 0));  // per wave and output tile: bf16 rows, fp8 rows, scale bytes
   bool stores_behind = false;  // the previous step ended with the 8 stores of a full output tile
   for (int q = 0; q < Q; ++q) {
     // stream position q has landed (only the DMA instructions of position q + 1 may still be in flight: 7 in waves 0-5, 6 in
     // waves 6-7) and everybody is done reading -- or, after an epilogue, transposing through -- the stage position q + 2 goes into
     if (q + 1 < Q) {
       // (stores count in vmcnt too: right after a full-tile epilogue its 8 store instructions are the newest operations)
-      if (stores_behind) {
+      if (stores_behind && n_epi_stores == 8) {
         if (w < 6) asm volatile("s_waitcnt vmcnt(15) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      } else if (stores_behind && n_epi_stores == 16) {
+        if (w < 6) asm volatile("s_waitcnt vmcnt(23) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(22) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      } else if (stores_behind) {
+        if (w < 6) asm volatile("s_waitcnt vmcnt(31) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(30) lgkmcnt(0)\n\ts_barrier" ::: "memory");
       } else {
         if (w < 6) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -231,13 +241,40 @@ __global__ __launch_bounds__(512, 2) void gemm_mx8_kernel(Mx8Args a) {
             bf16x8 o;
 #pragma unroll
             for (int i = 0; i < 4; ++i) { o[i] = (bf16_t)v0[i]; o[4 + i] = (bf16_t)v1[i]; }
-            *reinterpret_cast<bf16x8*>(a.Out + (size_t)m * a.ldo + n) = o;
+            if (a.Out) *reinterpret_cast<bf16x8*>(a.Out + (size_t)m * a.ldo + n) = o;
+          }
+          if (a.OutQ) {  // (uniform) quantise the bf16 values: a 32-column MX block is the four lanes of an aligned quad
+            float f[8], amax = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { f[i] = (float)(bf16_t)v0[i]; f[4 + i] = (float)(bf16_t)v1[i]; }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(f[i]));
+            amax = fmaxf(amax, dpp_mov<0xB1>(amax));
+            amax = fmaxf(amax, dpp_mov<0x4E>(amax));
+            int e8 = 127;
+            float inv = 1.f;
+            if (amax > 0.f) {  // as mx8_quantize_kernel
+              int ex = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xff) - 127 - 8;
+              if (amax * __builtin_bit_cast(float, (unsigned)(127 - ex) << 23) > 448.f) ex += 1;
+              ex = max(-127, min(127, ex));
+              e8 = ex + 127;
+              inv = __builtin_bit_cast(float, (unsigned)(127 - ex) << 23);
+            }
+            if (m < M) {
+              int p0 = 0, p1 = 0;
+              p0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0] * inv, f[1] * inv, p0, false);
+              p0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2] * inv, f[3] * inv, p0, true);
+              p1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4] * inv, f[5] * inv, p1, false);
+              p1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6] * inv, f[7] * inv, p1, true);
+              *reinterpret_cast<u32x2*>(a.OutQ + (size_t)m * a.N + n) = u32x2{(unsigned)p0, (unsigned)p1};
+              if ((l & 3) == 0) a.outs[(size_t)(n >> 5) * a.lds_o + m] = (uint8_t)e8;
+            }
           }
         }
       }
       ckt = 0;
       ++ctile;
-      stores_behind = m0 + MX_BM <= M;  // every lane stored: exactly 8 store instructions per wave
+      stores_behind = m0 + MX_BM <= M;  // every lane stored: exactly n_epi_stores store instructions per wave
     }
     st_rd = st_rd == MX_NSTG - 1 ? 0 : st_rd + 1;
     st_wr = st_wr == MX_NSTG - 1 ? 0 : st_wr + 1;
@@ -307,11 +344,25 @@ extern "C" int chadavit_mx8_quantize(const chada_bf16* x, int ldx, void* q, void
   return 0;
 }
 
+extern "C" int chadavit_gemm_nt_mx8_q(const void* Xq, const void* xs, int lds_x, const void* Wq, const void* ws, int lds_w, chada_bf16* Out,
+                                      int ldo, void* OutQ, void* out_scales, int lds_o, int M, int N, int K, const float* bias, int epilogue,
+                                      const chada_bf16* aux, int ldaux, void* stream);
+
 extern "C" int chadavit_gemm_nt_mx8(const void* Xq, const void* xs, int lds_x, const void* Wq, const void* ws, int lds_w, chada_bf16* Out,
                                     int ldo, int M, int N, int K, const float* bias, int epilogue, const chada_bf16* aux, int ldaux,
                                     void* stream) {
+  if (!Out) return 1;
+  return chadavit_gemm_nt_mx8_q(Xq, xs, lds_x, Wq, ws, lds_w, Out, ldo, nullptr, nullptr, 0, M, N, K, bias, epilogue, aux, ldaux, stream);
+}
+
+// ... with the result also (or only: Out == NULL) leaving as the next GEMM's fp8 X operand: OutQ [M, N] e4m3, out_scales [N/32, lds_o] e8m0
+extern "C" int chadavit_gemm_nt_mx8_q(const void* Xq, const void* xs, int lds_x, const void* Wq, const void* ws, int lds_w, chada_bf16* Out,
+                                      int ldo, void* OutQ, void* out_scales, int lds_o, int M, int N, int K, const float* bias, int epilogue,
+                                      const chada_bf16* aux, int ldaux, void* stream) {
   CHADA_ENTRY();
-  if (!Xq || !xs || !Wq || !ws || !Out || M <= 0 || N <= 0 || K <= 0) return 1;
+  if (!Xq || !xs || !Wq || !ws || (!Out && !OutQ) || M <= 0 || N <= 0 || K <= 0) return 1;
+  if (OutQ && (!out_scales || lds_o < M || ((uintptr_t)OutQ & 7) != 0)) return 1;
+  if (Out == nullptr) ldo = 8;
   if (N % MX_BN != 0 || K % MX_BK != 0 || ldo % 8 != 0 || (long long)M * K >= (1ll << 32) || (long long)N * K >= (1ll << 32)) return 2;
   if (lds_x < M || lds_w < N || lds_x % 4 != 0 || lds_w % 4 != 0 || (((uintptr_t)xs | (uintptr_t)ws) & 3) != 0) return 2;
   if (epilogue == MXE_RESID && (!aux || ldaux % 8 != 0)) return 1;
@@ -320,6 +371,7 @@ extern "C" int chadavit_gemm_nt_mx8(const void* Xq, const void* xs, int lds_x, c
   a.Wq = reinterpret_cast<const uint8_t*>(Wq); a.ws = reinterpret_cast<const uint8_t*>(ws);
   a.Out = reinterpret_cast<bf16_t*>(Out); a.bias = bias; a.aux = reinterpret_cast<const bf16_t*>(aux);
   a.M = M; a.N = N; a.K = K; a.ldo = ldo; a.ldaux = ldaux; a.lds_x = lds_x; a.lds_w = lds_w;
+  a.OutQ = reinterpret_cast<uint8_t*>(OutQ); a.outs = reinterpret_cast<uint8_t*>(out_scales); a.lds_o = lds_o;
   const int n_tiles = ((M + MX_BM - 1) / MX_BM) * (N / MX_BN);
   const dim3 grid(n_tiles < 256 ? n_tiles : 256);  // persistent: one 8-wave block per CU (150 KiB of LDS)
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -694,8 +694,10 @@ def mx8_quantize(x, relu=False, q=None, scales=None):
 
 
 @_timed(lambda xq, xs, wq, ws, *a, **k: ("gemm_nt_mx8", xq.shape[0], wq.shape[0], xq.shape[1], k.get("epilogue", 0)))
-def gemm_nt_mx8(xq, xs, wq, ws, bias=None, epilogue=EPI_NONE, aux=None, out=None):
-    """out[M,N] bf16 = epilogue(deq(xq, xs) @ deq(wq, ws)^T + bias) on the MX-scaled fp8 MFMA (epilogues NONE / RELU / RESID)."""
+def gemm_nt_mx8(xq, xs, wq, ws, bias=None, epilogue=EPI_NONE, aux=None, out=None, emit_q=False, want_out=True):
+    """out[M,N] bf16 = epilogue(deq(xq, xs) @ deq(wq, ws)^T + bias) on the MX-scaled fp8 MFMA (epilogues NONE / RELU / RESID).
+    emit_q: also return (q, scales) = mx8_quantize(out) produced by the epilogue itself (the next GEMM's operand); with want_out=False
+    the bf16 result is not written at all and None is returned in its place."""
     _req(xq, U8, "xq"); _req(wq, U8, "wq")
     M, K = xq.shape
     N = wq.shape[0]
@@ -704,18 +706,29 @@ def gemm_nt_mx8(xq, xs, wq, ws, bias=None, epilogue=EPI_NONE, aux=None, out=None
             raise RuntimeError(f"gemm_nt_mx8: {nm} must be the (K/32, rows) uint8 scale view mx8_quantize returns")
     if wq.shape[1] != K:
         raise RuntimeError("gemm_nt_mx8: operand shapes do not match")
-    if out is None:
+    if out is None and (want_out or not emit_q):
         out = torch.empty((M, N), device=xq.device, dtype=BF16)
-    _req(out, BF16, "out")
+    if out is not None:
+        _req(out, BF16, "out")
     if bias is not None:
         _req(bias, F32, "bias")
     if aux is not None:
         _req(aux, BF16, "aux")
-    rc = lib().chadavit_gemm_nt_mx8(_ptr(xq), _ptr(xs), c_int(xs.stride(0)), _ptr(wq), _ptr(ws), c_int(ws.stride(0)), _ptr(out),
-                                    c_int(out.stride(0)), c_int(M), c_int(N), c_int(K), _ptr(bias), c_int(epilogue), _ptr(aux),
-                                    c_int(aux.stride(0) if aux is not None else 0), _stream())
-    _chk(rc, "chadavit_gemm_nt_mx8")
-    return out
+    if not emit_q:
+        rc = lib().chadavit_gemm_nt_mx8(_ptr(xq), _ptr(xs), c_int(xs.stride(0)), _ptr(wq), _ptr(ws), c_int(ws.stride(0)), _ptr(out),
+                                        c_int(out.stride(0)), c_int(M), c_int(N), c_int(K), _ptr(bias), c_int(epilogue), _ptr(aux),
+                                        c_int(aux.stride(0) if aux is not None else 0), _stream())
+        _chk(rc, "chadavit_gemm_nt_mx8")
+        return out
+    if N % 32 != 0:
+        raise RuntimeError("gemm_nt_mx8: emit_q needs N % 32 == 0")
+    oq = torch.empty((M, N), device=xq.device, dtype=U8)
+    osc = torch.empty((N // 32, (M + 3) // 4 * 4), device=xq.device, dtype=U8)[:, :M]
+    rc = lib().chadavit_gemm_nt_mx8_q(_ptr(xq), _ptr(xs), c_int(xs.stride(0)), _ptr(wq), _ptr(ws), c_int(ws.stride(0)), _ptr(out),
+                                      c_int(out.stride(0) if out is not None else 0), _ptr(oq), _ptr(osc), c_int(osc.stride(0)), c_int(M), c_int(N),
+                                      c_int(K), _ptr(bias), c_int(epilogue), _ptr(aux), c_int(aux.stride(0) if aux is not None else 0), _stream())
+    _chk(rc, "chadavit_gemm_nt_mx8_q")
+    return out, (oq, osc)
 
 
 # ---- device augmentation ---------------------------------------------------------------------------------------

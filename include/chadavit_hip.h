@@ -294,6 +294,12 @@ int chadavit_mx8_quantize(const chada_bf16* x, int ldx, void* q, void* scales, i
  * xs [K/32, lds_x], ws [K/32, lds_w] as written by chadavit_mx8_quantize.  N % 128 == 0, K % 128 == 0. */
 int chadavit_gemm_nt_mx8(const void* Xq, const void* xs, int lds_x, const void* Wq, const void* ws, int lds_w, chada_bf16* Out, int ldo,
                          int M, int N, int K, const float* bias, int epilogue, const chada_bf16* aux, int ldaux, void* stream);
+/* The same GEMM with its result ALSO (or, Out == NULL, ONLY) written as the next GEMM's OCP-MX operand: OutQ [M, N] e4m3 and
+ * out_scales [N/32, lds_o] e8m0 (lds_o >= M), bit-identical to chadavit_mx8_quantize applied to Out -- linear1's epilogue feeding linear2
+ * (chada_vit.py:113-115) without the quantise pass over the hidden activation. */
+int chadavit_gemm_nt_mx8_q(const void* Xq, const void* xs, int lds_x, const void* Wq, const void* ws, int lds_w, chada_bf16* Out, int ldo,
+                           void* OutQ, void* out_scales, int lds_o, int M, int N, int K, const float* bias, int epilogue,
+                           const chada_bf16* aux, int ldaux, void* stream);
 
 /* ---- device side of the multi-crop augmentation contract (build_transform_pipeline, src/data/pretrain_dataloader.py:272-328) -------
  * chadavit_crop_resize: RandomResizedCrop / Resize with cv2.INTER_CUBIC (+ CustomColorJitter, src/data/custom_transforms.py:301-351,

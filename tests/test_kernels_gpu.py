@@ -757,3 +757,23 @@ def test_gemm_nt_mx8(M, N, K):
     exact = x.float() @ w.float().t()
     rel = float((ref - exact).norm() / exact.norm())
     assert rel <= 6e-2, rel
+
+
+@pytest.mark.parametrize("M", [1000, 257])
+def test_gemm_nt_mx8_emits_the_next_operand(M):
+    """The ReLU epilogue of the MX-fp8 GEMM hands the next GEMM its operand: (bytes, scales) bit-identical to mx8_quantize applied to the
+    bf16 result, with and without the bf16 result being written."""
+    from chadavit_amd import ops
+    dev = _dev()
+    N, K = 3072, 768
+    x = _rand((M, K), 201, 1.0).bfloat16().to(dev)
+    w = (_rand((N, K), 202, 1.0) / math.sqrt(K)).bfloat16().to(dev)
+    bias = _rand((N,), 203, 0.2).to(dev)
+    xq, xs = ops.mx8_quantize(x)
+    wq, ws = ops.mx8_quantize(w)
+    ref = ops.gemm_nt_mx8(xq, xs, wq, ws, bias=bias, epilogue=ops.EPI_RELU)
+    rq, rs = ops.mx8_quantize(ref)
+    out, (q, sc) = ops.gemm_nt_mx8(xq, xs, wq, ws, bias=bias, epilogue=ops.EPI_RELU, emit_q=True)
+    assert torch.equal(out, ref) and torch.equal(q, rq) and torch.equal(sc, rs)
+    none, (q2, sc2) = ops.gemm_nt_mx8(xq, xs, wq, ws, bias=bias, epilogue=ops.EPI_RELU, emit_q=True, want_out=False)
+    assert none is None and torch.equal(q2, rq) and torch.equal(sc2, rs)
