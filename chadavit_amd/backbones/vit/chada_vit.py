@@ -13,6 +13,7 @@ they give the reference's parameter names and initial distributions; their forwa
 from __future__ import annotations
 
 import math
+import os
 from functools import partial
 from typing import List, Optional, Sequence
 
@@ -117,6 +118,7 @@ class ChAdaViT(nn.Module):
         # MFMA -- weights AND their input activations quantised to OCP-MX e4m3 (BASELINE.json configs[4], ChAda-ViT-Base); the
         # backward keeps bf16 operands.  Needs embed_dim % 128 == 0.
         self.weight_dtype = "bf16"
+        self.fp8_ln_emits_operand = True  # fp8 path: LayerNorm kernels also emit the following GEMM's quantised operand (measured neutral)
         self._capture_blocks = None  # tests: {block index: None} -> filled with that block's output (packed rows) by the forward
 
     @staticmethod
@@ -247,6 +249,8 @@ class ChAdaViT(nn.Module):
             xcur, _, hcur, stcur, qcur = _block_fwd(self, flat, i, xcur, rb, False, h=hcur, st=stcur, qkv=qcur)
         b = f"blocks.{last}."
         qkv = qcur  # (already produced by the previous block's kernel where that is fused)
+        if isinstance(hcur, tuple):  # (fp8 weight path: (h, its quantised copy))
+            hcur = hcur[0]
         if qkv is None:
             if hcur is None:  # depth 1: no previous block computed norm1 of this one
                 hcur = ops.layernorm_fwd(xcur, flat.f(b + "norm1.weight"), flat.f(b + "norm1.bias"), self.blocks[last].norm1.eps)
@@ -302,16 +306,28 @@ def _block_fwd(m: ChAdaViT, flat: FlatParams, i: int, x, rb: RaggedBatch, save: 
     if st is None:
         st = torch.empty((6, T), device=dev, dtype=torch.float32) if save else None
     g1, b1 = flat.f(b + "norm1.weight"), flat.f(b + "norm1.bias")
+    # fp8 weight path: the LayerNorm kernels hand the following GEMM its quantised operand (no separate quantise pass)
+    fq = m.weight_dtype == "fp8" and x.shape[1] in ops.LN_PAIR_WIDTHS and m.fp8_ln_emits_operand
+    hq = None
+    if isinstance(h, tuple):
+        h, hq = h
     if h is None and qkv is None:
-        h = ops.layernorm_fwd(x, g1, b1, eps, mean=st[0] if save else None, rstd=st[1] if save else None)
+        if fq:
+            h, hq = ops.layernorm_fwd(x, g1, b1, eps, mean=st[0] if save else None, rstd=st[1] if save else None, emit_q=True)
+        else:
+            h = ops.layernorm_fwd(x, g1, b1, eps, mean=st[0] if save else None, rstd=st[1] if save else None)
     if qkv is None:  # (else: produced by the previous block's kernel)
-        qkv = _linear(m, flat, h, b + "self_attn.in_proj_weight", flat.f(b + "self_attn.in_proj_bias"))
+        qkv = _linear(m, flat, h, b + "self_attn.in_proj_weight", flat.f(b + "self_attn.in_proj_bias"), xq=hq)
     a, lse = ops.attn_fwd(qkv, rb.cu_seqlens, rb.work, H)
     pk = flat.ffn_packed(b + "linear1.weight") if (T >= m.fused_min_rows and m.weight_dtype != "fp8") else None
     pkp = flat.proj_ffn_packed(b + "linear1.weight") if pk is not None else None
     if pkp is None:
         y = _linear(m, flat, a, b + "self_attn.out_proj.weight", flat.f(b + "self_attn.out_proj.bias"), ops.EPI_RESID, x)
-        x1 = ops.layernorm_fwd(y, g1, b1, eps, mean=st[2] if save else None, rstd=st[3] if save else None)
+        x1q = None
+        if fq:
+            x1, x1q = ops.layernorm_fwd(y, g1, b1, eps, mean=st[2] if save else None, rstd=st[3] if save else None, emit_q=True)
+        else:
+            x1 = ops.layernorm_fwd(y, g1, b1, eps, mean=st[2] if save else None, rstd=st[3] if save else None)
     last = i + 1 >= len(m.blocks)
     h_next = st_next = qkv_next = rbits = None
     ln2 = (flat.f(b + "norm2.weight"), flat.f(b + "norm2.bias"), m.blocks[i].norm2.eps)
@@ -349,12 +365,17 @@ def _block_fwd(m: ChAdaViT, flat: FlatParams, i: int, x, rb: RaggedBatch, save: 
         if m.weight_dtype == "fp8":
             # linear1's epilogue hands linear2 its fp8 operand (no quantise pass over the hidden activation); the bf16 copy is written
             # only when the backward needs it
-            hid, hq = _linear(m, flat, x1, b + "linear1.weight", flat.f(b + "linear1.bias"), ops.EPI_RELU, emit_q=True, want_out=save)
-            z = _linear(m, flat, hid, b + "linear2.weight", flat.f(b + "linear2.bias"), ops.EPI_RESID, x1, xq=hq)
+            hid, hidq = _linear(m, flat, x1, b + "linear1.weight", flat.f(b + "linear1.bias"), ops.EPI_RELU, xq=x1q, emit_q=True, want_out=save)
+            z = _linear(m, flat, hid, b + "linear2.weight", flat.f(b + "linear2.bias"), ops.EPI_RESID, x1, xq=hidq)
         else:
             hid = _linear(m, flat, x1, b + "linear1.weight", flat.f(b + "linear1.bias"), ops.EPI_RELU)
             z = _linear(m, flat, hid, b + "linear2.weight", flat.f(b + "linear2.bias"), ops.EPI_RESID, x1)
-        if not last:
+        if not last and fq:
+            x2, h_next, hq_next = ops.layernorm_fwd2(z, ln2[0], ln2[1], ln1n[0], ln1n[1], ln2[2], ln1n[2],
+                                                     stats1=(st[4], st[5]) if save else None,
+                                                     stats2=(st_next[0], st_next[1]) if save else None, emit_q=True)
+            h_next = (h_next, hq_next)  # the next block unpacks it
+        elif not last:
             x2, h_next = ops.layernorm_fwd2(z, ln2[0], ln2[1], ln1n[0], ln1n[1], ln2[2], ln1n[2],
                                             stats1=(st[4], st[5]) if save else None, stats2=(st_next[0], st_next[1]) if save else None)
         else:

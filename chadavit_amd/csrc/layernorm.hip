@@ -283,10 +283,44 @@ __device__ __forceinline__ f32x4 ln_apply(const f32x4& v, float mean, float rstd
   return o;
 }
 
+// OCP-MX quantisation of a freshly normalised row, for the fp8 weight path (gemm_mx8.hip): the lane's four consecutive columns of
+// group j belong to the 32-column block of its aligned group of EIGHT lanes -- block maximum by three DPP steps, then the same scale
+// rule, conversion and layout as mx8_quantize_kernel (bit-identical to quantising the stored bf16 row in a separate pass).
 template <int QD>
+__device__ __forceinline__ void mx_emit_row(const bf16x4 (&ob)[3], const QuadRow<QD>& q, uint8_t* __restrict__ yq, uint8_t* __restrict__ ys,
+                                            int lds, int row, bool live) {
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    float f[4], amax = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { f[k] = (float)ob[j][k]; amax = fmaxf(amax, fabsf(f[k])); }
+    amax = fmaxf(amax, dpp_mov<0xB1>(amax));   // lane ^ 1
+    amax = fmaxf(amax, dpp_mov<0x4E>(amax));   // lane ^ 2
+    amax = fmaxf(amax, dpp_mov<0x141>(amax));  // row_half_mirror: the other quad of the eight
+    int e8 = 127;
+    float inv = 1.f;
+    if (amax > 0.f) {
+      int ex = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xff) - 127 - 8;
+      if (amax * __builtin_bit_cast(float, (unsigned)(127 - ex) << 23) > 448.f) ex += 1;
+      ex = max(-127, min(127, ex));
+      e8 = ex + 127;
+      inv = __builtin_bit_cast(float, (unsigned)(127 - ex) << 23);
+    }
+    if (live) {
+      int pk = 0;
+      pk = __builtin_amdgcn_cvt_pk_fp8_f32(f[0] * inv, f[1] * inv, pk, false);
+      pk = __builtin_amdgcn_cvt_pk_fp8_f32(f[2] * inv, f[3] * inv, pk, true);
+      *reinterpret_cast<unsigned*>(yq + (size_t)row * QD + q.col(j)) = (unsigned)pk;
+      if ((q.sub & 7) == 0) ys[(size_t)(q.col(j) >> 5) * lds + row] = (uint8_t)e8;
+    }
+  }
+}
+
+template <int QD, bool EMITQ = false>
 __global__ __launch_bounds__(256) void ln_fwd_quad_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, bf16_t* __restrict__ y,
-                                                          float* __restrict__ mean_out, float* __restrict__ rstd_out, int T, float eps) {
+                                                          float* __restrict__ mean_out, float* __restrict__ rstd_out, int T, float eps,
+                                                          uint8_t* __restrict__ yq = nullptr, uint8_t* __restrict__ ys = nullptr, int lds = 0) {
   using QR = QuadRow<QD>;
   const QR q;
   const int w = threadIdx.x >> 6;
@@ -306,27 +340,32 @@ __global__ __launch_bounds__(256) void ln_fwd_quad_kernel(const bf16_t* __restri
     for (int j = 0; j < 3; ++j) v[j] = ld4(xr + q.col(j));
     const float mean = QR::rsum(hsum(v[0]) + hsum(v[1]) + hsum(v[2])) * invD;
     const float rstd = rsqrtf(QR::rsum(sqdev(v, mean)) * invD + eps);
+    bf16x4 ob[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const f32x4 o = ln_apply(v[j], mean, rstd, gm[j], bt[j]);
+      ob[j] = pack4(o[0], o[1], o[2], o[3]);
+    }
     if (live) {
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const f32x4 o = ln_apply(v[j], mean, rstd, gm[j], bt[j]);
-        *reinterpret_cast<bf16x4*>(y + (size_t)row * QD + q.col(j)) = pack4(o[0], o[1], o[2], o[3]);
-      }
+      for (int j = 0; j < 3; ++j) *reinterpret_cast<bf16x4*>(y + (size_t)row * QD + q.col(j)) = ob[j];
       if (q.sub == 0) {
         if (mean_out) mean_out[row] = mean;
         if (rstd_out) rstd_out[row] = rstd;
       }
     }
+    if constexpr (EMITQ) mx_emit_row<QD>(ob, q, yq, ys, lds, row, live);
   }
 }
 
-template <int QD>
+template <int QD, bool EMITQ = false>
 __global__ __launch_bounds__(256) void ln_fwd2_quad_kernel(const bf16_t* __restrict__ x, const float* __restrict__ ga,
                                                            const float* __restrict__ ba, const float* __restrict__ gb,
                                                            const float* __restrict__ bb, bf16_t* __restrict__ y1,
                                                            bf16_t* __restrict__ y2, float* __restrict__ mean1,
                                                            float* __restrict__ rstd1, float* __restrict__ mean2,
-                                                           float* __restrict__ rstd2, int T, float eps_a, float eps_b) {
+                                                           float* __restrict__ rstd2, int T, float eps_a, float eps_b,
+                                                           uint8_t* __restrict__ yq = nullptr, uint8_t* __restrict__ ys = nullptr, int lds = 0) {
   using QR = QuadRow<QD>;
   const QR q;
   const int w = threadIdx.x >> 6;
@@ -357,17 +396,21 @@ __global__ __launch_bounds__(256) void ln_fwd2_quad_kernel(const bf16_t* __restr
     }
     const float m2 = QR::rsum(hsum(v[0]) + hsum(v[1]) + hsum(v[2])) * invD;
     const float r2 = rsqrtf(QR::rsum(sqdev(v, m2)) * invD + eps_b);
+    bf16x4 ob[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const f32x4 o = ln_apply(v[j], m2, r2, g2[j], b2[j]);
+      ob[j] = pack4(o[0], o[1], o[2], o[3]);
+    }
     if (live) {
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const f32x4 o = ln_apply(v[j], m2, r2, g2[j], b2[j]);
-        *reinterpret_cast<bf16x4*>(y2 + (size_t)row * QD + q.col(j)) = pack4(o[0], o[1], o[2], o[3]);
-      }
+      for (int j = 0; j < 3; ++j) *reinterpret_cast<bf16x4*>(y2 + (size_t)row * QD + q.col(j)) = ob[j];
       if (q.sub == 0) {
         if (mean1) { mean1[row] = m1; rstd1[row] = r1; }
         if (mean2) { mean2[row] = m2; rstd2[row] = r2; }
       }
     }
+    if constexpr (EMITQ) mx_emit_row<QD>(ob, q, yq, ys, lds, row, live);  // the second norm's output: the next block's in_proj operand
   }
 }
 
@@ -667,6 +710,52 @@ extern "C" int chadavit_layernorm_bwd_pair(const chada_bf16* dy, const chada_bf1
   hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * D + 15) / 16), dim3(256), 0, s, pa, dgamma_a, dbeta_a, gq, D, accumulate_a);
   CHADA_CHECK_LAUNCH();
   hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * D + 15) / 16), dim3(256), 0, s, pb, dgamma_b, dbeta_b, gq, D, accumulate_b);
+  CHADA_CHECK_LAUNCH();
+  return 0;
+}
+
+// LayerNorm forward that also emits its output as an OCP-MX fp8 operand (yq [T, D] e4m3, ys [D/32, lds] e8m0, lds >= T): what
+// chadavit_mx8_quantize(y) would produce, without the pass over y.  D in {192, 384, 768}.
+extern "C" int chadavit_layernorm_fwd_q(const chada_bf16* x, const float* gamma, const float* beta, chada_bf16* y, float* mean, float* rstd,
+                                        void* yq, void* ys, int lds, int T, int D, float eps, void* stream) {
+  CHADA_ENTRY();
+  if (!x || !gamma || !beta || !y || !yq || !ys || T <= 0 || lds < T) return 1;
+  if (D != 192 && D != 384 && D != 768) return 2;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int rpb = 4 * (768 / D);
+  int gq = (T + rpb - 1) / rpb;
+  if (gq > 4096) gq = 4096;
+  const bf16_t* xx = reinterpret_cast<const bf16_t*>(x);
+  bf16_t* yy = reinterpret_cast<bf16_t*>(y);
+  uint8_t* q8 = reinterpret_cast<uint8_t*>(yq);
+  uint8_t* s8 = reinterpret_cast<uint8_t*>(ys);
+  if (D == 192) hipLaunchKernelGGL((ln_fwd_quad_kernel<192, true>), dim3(gq), dim3(256), 0, s, xx, gamma, beta, yy, mean, rstd, T, eps, q8, s8, lds);
+  else if (D == 384) hipLaunchKernelGGL((ln_fwd_quad_kernel<384, true>), dim3(gq), dim3(256), 0, s, xx, gamma, beta, yy, mean, rstd, T, eps, q8, s8, lds);
+  else hipLaunchKernelGGL((ln_fwd_quad_kernel<768, true>), dim3(gq), dim3(256), 0, s, xx, gamma, beta, yy, mean, rstd, T, eps, q8, s8, lds);
+  CHADA_CHECK_LAUNCH();
+  return 0;
+}
+
+// ... and the two chained LayerNorms with the SECOND output (the next block's norm1) emitted as an fp8 operand
+extern "C" int chadavit_layernorm_fwd2_q(const chada_bf16* x, const float* gamma_a, const float* beta_a, const float* gamma_b,
+                                         const float* beta_b, chada_bf16* y1, chada_bf16* y2, float* mean1, float* rstd1, float* mean2,
+                                         float* rstd2, void* y2q, void* y2s, int lds, int T, int D, float eps_a, float eps_b, void* stream) {
+  CHADA_ENTRY();
+  if (!x || !gamma_a || !beta_a || !gamma_b || !beta_b || !y1 || !y2 || !y2q || !y2s || T <= 0 || lds < T) return 1;
+  if ((mean1 == nullptr) != (rstd1 == nullptr) || (mean2 == nullptr) != (rstd2 == nullptr)) return 1;
+  if (D != 192 && D != 384 && D != 768) return 2;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int rpb = 4 * (768 / D);
+  int gq = (T + rpb - 1) / rpb;
+  if (gq > 4096) gq = 4096;
+  const bf16_t* xx = reinterpret_cast<const bf16_t*>(x);
+  bf16_t* o1 = reinterpret_cast<bf16_t*>(y1);
+  bf16_t* o2 = reinterpret_cast<bf16_t*>(y2);
+  uint8_t* q8 = reinterpret_cast<uint8_t*>(y2q);
+  uint8_t* s8 = reinterpret_cast<uint8_t*>(y2s);
+#define LN2QQ(DV) hipLaunchKernelGGL((ln_fwd2_quad_kernel<DV, true>), dim3(gq), dim3(256), 0, s, xx, gamma_a, beta_a, gamma_b, beta_b, o1, o2, mean1, rstd1, mean2, rstd2, T, eps_a, eps_b, q8, s8, lds)
+  if (D == 192) LN2QQ(192); else if (D == 384) LN2QQ(384); else LN2QQ(768);
+#undef LN2QQ
   CHADA_CHECK_LAUNCH();
   return 0;
 }

@@ -354,12 +354,23 @@ def write_cls(tokens, cu, cls, pos0):
     _chk(lib().chadavit_write_cls(_ptr(tokens), _ptr(cu), _ptr(cls), _ptr(pos0), c_int(B), c_int(D), _stream()), "chadavit_write_cls")
 
 
+def _mx_out(T, D, device):
+    return torch.empty((T, D), device=device, dtype=U8), torch.empty((D // 32, (T + 3) // 4 * 4), device=device, dtype=U8)[:, :T]
+
+
 @_timed(lambda x, *a, **k: ("layernorm_fwd", x.shape[0], x.shape[1]))
-def layernorm_fwd(x, gamma, beta, eps, out=None, mean=None, rstd=None):
+def layernorm_fwd(x, gamma, beta, eps, out=None, mean=None, rstd=None, emit_q=False):
+    """emit_q (D in 192 / 384 / 768): returns (y, (bytes, scales)) with y also quantised as an OCP-MX fp8 operand (= mx8_quantize(y))."""
     _req(x, BF16, "x"); _req(gamma, F32, "gamma"); _req(beta, F32, "beta")
     T, D = x.shape
     if out is None:
         out = torch.empty_like(x)
+    if emit_q:
+        yq, ys = _mx_out(T, D, x.device)
+        rc = lib().chadavit_layernorm_fwd_q(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(out), _ptr(mean), _ptr(rstd), _ptr(yq), _ptr(ys),
+                                            c_int(ys.stride(0)), c_int(T), c_int(D), c_float(eps), _stream())
+        _chk(rc, "chadavit_layernorm_fwd_q")
+        return out, (yq, ys)
     rc = lib().chadavit_layernorm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(out), _ptr(mean), _ptr(rstd), c_int(T), c_int(D),
                                       c_float(eps), _stream())
     _chk(rc, "chadavit_layernorm_fwd")
@@ -367,14 +378,21 @@ def layernorm_fwd(x, gamma, beta, eps, out=None, mean=None, rstd=None):
 
 
 @_timed(lambda x, *a, **k: ("layernorm_fwd2", x.shape[0], x.shape[1]))
-def layernorm_fwd2(x, ga, ba, gb, bb, eps_a, eps_b, stats1=None, stats2=None):
-    """y1 = LN_a(x); y2 = LN_b(y1) in one pass.  stats*: (mean, rstd) tensors or None."""
+def layernorm_fwd2(x, ga, ba, gb, bb, eps_a, eps_b, stats1=None, stats2=None, emit_q=False):
+    """y1 = LN_a(x); y2 = LN_b(y1) in one pass.  stats*: (mean, rstd) tensors or None.  emit_q: returns (y1, y2, (bytes, scales) of y2)."""
     _req(x, BF16, "x")
     T, D = x.shape
     y1 = torch.empty_like(x)
     y2 = torch.empty_like(x)
     m1, r1 = stats1 if stats1 is not None else (None, None)
     m2, r2 = stats2 if stats2 is not None else (None, None)
+    if emit_q:
+        yq, ys = _mx_out(T, D, x.device)
+        rc = lib().chadavit_layernorm_fwd2_q(_ptr(x), _ptr(ga), _ptr(ba), _ptr(gb), _ptr(bb), _ptr(y1), _ptr(y2), _ptr(m1), _ptr(r1), _ptr(m2),
+                                             _ptr(r2), _ptr(yq), _ptr(ys), c_int(ys.stride(0)), c_int(T), c_int(D), c_float(eps_a),
+                                             c_float(eps_b), _stream())
+        _chk(rc, "chadavit_layernorm_fwd2_q")
+        return y1, y2, (yq, ys)
     rc = lib().chadavit_layernorm_fwd2(_ptr(x), _ptr(ga), _ptr(ba), _ptr(gb), _ptr(bb), _ptr(y1), _ptr(y2), _ptr(m1), _ptr(r1), _ptr(m2),
                                        _ptr(r2), c_int(T), c_int(D), c_float(eps_a), c_float(eps_b), _stream())
     _chk(rc, "chadavit_layernorm_fwd2")

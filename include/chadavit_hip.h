@@ -91,6 +91,14 @@ int chadavit_layernorm_fwd(const chada_bf16* x, const float* gamma, const float*
 int chadavit_layernorm_fwd2(const chada_bf16* x, const float* gamma_a, const float* beta_a, const float* gamma_b,
                             const float* beta_b, chada_bf16* y1, chada_bf16* y2, float* mean1, float* rstd1, float* mean2,
                             float* rstd2, int T, int D, float eps_a, float eps_b, void* stream);
+/* The two forward entry points above with the (second) output ALSO emitted as an OCP-MX fp8 operand for the fp8 weight path
+ * (yq [T, D] e4m3, ys [D/32, lds] e8m0 with lds >= T): bit-identical to chadavit_mx8_quantize applied to y / y2, without the pass over it.
+ * D in {192, 384, 768} (rc 2 otherwise). */
+int chadavit_layernorm_fwd_q(const chada_bf16* x, const float* gamma, const float* beta, chada_bf16* y, float* mean, float* rstd,
+                             void* yq, void* ys, int lds, int T, int D, float eps, void* stream);
+int chadavit_layernorm_fwd2_q(const chada_bf16* x, const float* gamma_a, const float* beta_a, const float* gamma_b, const float* beta_b,
+                              chada_bf16* y1, chada_bf16* y2, float* mean1, float* rstd1, float* mean2, float* rstd2, void* y2q,
+                              void* y2s, int lds, int T, int D, float eps_a, float eps_b, void* stream);
 int chadavit_layernorm_bwd(const chada_bf16* dy, const chada_bf16* x, const float* mean, const float* rstd,
                            const float* gamma, const chada_bf16* dres, chada_bf16* dx, float* dgamma, float* dbeta,
                            int accumulate, int T, int D, float* workspace, void* stream);

@@ -777,3 +777,22 @@ def test_gemm_nt_mx8_emits_the_next_operand(M):
     assert torch.equal(out, ref) and torch.equal(q, rq) and torch.equal(sc, rs)
     none, (q2, sc2) = ops.gemm_nt_mx8(xq, xs, wq, ws, bias=bias, epilogue=ops.EPI_RELU, emit_q=True, want_out=False)
     assert none is None and torch.equal(q2, rq) and torch.equal(sc2, rs)
+
+
+@pytest.mark.parametrize("T,D", [(1000, 768), (333, 384), (77, 192)])
+def test_layernorm_fwd_emits_fp8_operand(T, D):
+    """LayerNorm forward kernels that also emit their output as an OCP-MX fp8 operand: bit-identical to mx8_quantize of the bf16 output
+    (single norm and the second output of the chained pair), the bf16 outputs and statistics unchanged."""
+    from chadavit_amd import ops
+    dev = _dev()
+    x = _rand((T, D), 301, 2.0).bfloat16().to(dev)
+    ga, ba = (1 + _rand((D,), 302, 0.2)).to(dev), _rand((D,), 303, 0.2).to(dev)
+    gb, bb = (1 + _rand((D,), 304, 0.2)).to(dev), _rand((D,), 305, 0.2).to(dev)
+    y = ops.layernorm_fwd(x, ga, ba, 1e-5)
+    rq, rs = ops.mx8_quantize(y)
+    y2, (q, sc) = ops.layernorm_fwd(x, ga, ba, 1e-5, emit_q=True)
+    assert torch.equal(y2, y) and torch.equal(q, rq) and torch.equal(sc, rs)
+    a1, a2 = ops.layernorm_fwd2(x, ga, ba, gb, bb, 1e-5, 1e-5)
+    r2q, r2s = ops.mx8_quantize(a2)
+    b1, b2, (q2, s2) = ops.layernorm_fwd2(x, ga, ba, gb, bb, 1e-5, 1e-5, emit_q=True)
+    assert torch.equal(b1, a1) and torch.equal(b2, a2) and torch.equal(q2, r2q) and torch.equal(s2, r2s)
