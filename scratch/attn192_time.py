@@ -1,5 +1,5 @@
 import sys, torch, ctypes
-sys.path.insert(0, '.')
+sys.path.insert(0, sys.argv[1] if len(sys.argv) > 1 else '.')
 from chadavit_amd import ops
 from chadavit_amd._lib import lib
 from chadavit_amd.ragged import RaggedBatch

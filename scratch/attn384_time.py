@@ -1,5 +1,5 @@
 import sys, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, sys.argv[1] if len(sys.argv) > 1 else '.')
 from chadavit_amd import ops
 from chadavit_amd.ragged import RaggedBatch
 dev = torch.device('cuda:0'); bf = torch.bfloat16
