@@ -255,7 +255,8 @@ extern "C" int chadavit_tokenizer_bwd(const chada_bf16* dtok_, const int* cu_seq
   const int Mp = n_chan * p;
   hipLaunchKernelGGL(tokbwd_compact_kernel, dim3(grid_for((size_t)Mp * D / 8, 8192)), dim3(256), 0, s, dtok, chan_img, dpatch,
                      Mp, p, D);
-  if (n_chan > TOKB_MAXLIST || (B + max_channels - 1) / max_channels > TOKB_MAXLIST) return 2;
+  // a (patch position, channel slot) block lists the channel instances of ITS slot: at most one per image
+  if (B > TOKB_MAXLIST) return 2;
   hipLaunchKernelGGL(tokbwd_slot_kernel, dim3(p + 1, max_channels), dim3(256), 0, s, dtok, cu_seqlens, chan_img, chan_idx, workspace, B,
                      n_chan, p, D, max_channels);
   hipLaunchKernelGGL(tokbwd_finish_kernel, dim3(p + max_channels + 1), dim3(256), 0, s, workspace, dpos, dchan, dcls, p, max_channels, D);
