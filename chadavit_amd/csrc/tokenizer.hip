@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void tokbwd_compact_kernel(const bf16_t* __res
 //     instance list with one dependent load per iteration and was latency-bound (168 us for 58 MB).  A lane owns 4 consecutive
 //     columns (8-byte loads); partials meet in LDS.  Everything the tokenizer's parameter gradients need is a marginal:
 //       dpos[j] = sum_c slot[c][j]      dchan[c] = sum_j slot[c][j]      dcls = sum_c slot[c][p]
-constexpr int TOKB_MAXLIST = 4096;  // rows one (j, c) block can sum: channel instances of one slot / images of one CLS share
+constexpr int TOKB_MAXLIST = 4096;  // rows one (j, c) block lists at a time (larger batches go through in windows)
 __global__ __launch_bounds__(256) void tokbwd_slot_kernel(const bf16_t* __restrict__ dtok, const int* __restrict__ cu,
                                                           const int* __restrict__ chan_img, const int* __restrict__ chan_idx,
                                                           float* __restrict__ slot, int B, int n_chan, int p, int D, int max_c) {
@@ -98,55 +98,70 @@ __global__ __launch_bounds__(256) void tokbwd_slot_kernel(const bf16_t* __restri
   __shared__ int wcnt[4];
   __shared__ f32x4 red[4][64];
   const int j = blockIdx.x, c = blockIdx.y, tid = threadIdx.x, l = tid & 63, w = tid >> 6;
-  // ordered compaction (ballot prefix, no atomics): the list -- and with it the summation order -- is the same on every run
+  // ordered compaction (ballot prefix, no atomics): the list -- and with it the summation order -- is the same on every run.
+  // Items are taken in windows of TOKB_MAXLIST (a window's hits always fit the list); the sums carry over in registers.
   const int n_items = j < p ? n_chan : (B - c + max_c - 1) / max_c;
-  int n = 0;
-  for (int g0 = 0; g0 < n_items; g0 += 256) {
-    const int idx = g0 + tid;
-    bool hit = false;
-    int row = 0;
-    if (idx < n_items) {
-      if (j < p) {
-        hit = chan_idx[idx] == c;
-        row = idx * p + j + chan_img[idx] + 1;
-      } else {
-        hit = true;
-        row = cu[c + idx * max_c];
+  f32x4 acc[4];  // D <= 1024: up to four 256-column slices per lane
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int base = 0; base < n_items; base += TOKB_MAXLIST) {
+    const int lim = min(n_items, base + TOKB_MAXLIST);
+    int n = 0;
+    for (int g0 = base; g0 < lim; g0 += 256) {
+      const int idx = g0 + tid;
+      bool hit = false;
+      int row = 0;
+      if (idx < lim) {
+        if (j < p) {
+          hit = chan_idx[idx] == c;
+          row = idx * p + j + chan_img[idx] + 1;
+        } else {
+          hit = true;
+          row = cu[c + idx * max_c];
+        }
+      }
+      const unsigned long long bal = __ballot(hit);
+      if (l == 0) wcnt[w] = __popcll(bal);
+      __syncthreads();
+      int woff = 0;
+      for (int q = 0; q < w; ++q) woff += wcnt[q];
+      const int at = n + woff + __popcll(bal & ((1ull << l) - 1ull));
+      if (hit) rows[at] = row;
+      n += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+      __syncthreads();
+    }
+#pragma unroll
+    for (int di = 0; di < 4; ++di) {
+      const int d = di * 256 + 4 * l;
+      if (d < D) {
+        f32x4 s = acc[di];
+        int k = w;
+        for (; k + 28 < n; k += 32) {  // 8 rows per wave and step: independent loads
+          bf16x4 v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const bf16x4*>(dtok + (size_t)rows[k + 4 * u] * D + d);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { s[0] += (float)v[u][0]; s[1] += (float)v[u][1]; s[2] += (float)v[u][2]; s[3] += (float)v[u][3]; }
+        }
+        for (; k < n; k += 4) {
+          const bf16x4 v = *reinterpret_cast<const bf16x4*>(dtok + (size_t)rows[k] * D + d);
+          s[0] += (float)v[0]; s[1] += (float)v[1]; s[2] += (float)v[2]; s[3] += (float)v[3];
+        }
+        acc[di] = s;
       }
     }
-    const unsigned long long bal = __ballot(hit);
-    if (l == 0) wcnt[w] = __popcll(bal);
-    __syncthreads();
-    int woff = 0;
-    for (int q = 0; q < w; ++q) woff += wcnt[q];
-    const int at = n + woff + __popcll(bal & ((1ull << l) - 1ull));
-    if (hit && at < TOKB_MAXLIST) rows[at] = row;
-    n += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-    __syncthreads();
+    __syncthreads();  // the list is rebuilt by the next window
   }
-  n = min(n, TOKB_MAXLIST);  // (the launcher rejects batches that could exceed the list)
-  for (int d0 = 0; d0 < D; d0 += 256) {
-    const int d = d0 + 4 * l;
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    if (d < D) {
-      int k = w;
-      for (; k + 28 < n; k += 32) {  // 8 rows per wave and step: independent loads
-        bf16x4 v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const bf16x4*>(dtok + (size_t)rows[k + 4 * u] * D + d);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { s[0] += (float)v[u][0]; s[1] += (float)v[u][1]; s[2] += (float)v[u][2]; s[3] += (float)v[u][3]; }
-      }
-      for (; k < n; k += 4) {
-        const bf16x4 v = *reinterpret_cast<const bf16x4*>(dtok + (size_t)rows[k] * D + d);
-        s[0] += (float)v[0]; s[1] += (float)v[1]; s[2] += (float)v[2]; s[3] += (float)v[3];
-      }
+  for (int di = 0; di < 4; ++di) {
+    const int d = di * 256 + 4 * l;
+    if (di * 256 < D) {
+      red[w][l] = acc[di];
+      __syncthreads();
+      if (w == 0 && d < D)
+        *reinterpret_cast<f32x4*>(slot + ((size_t)c * (p + 1) + j) * D + d) = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+      __syncthreads();
     }
-    red[w][l] = s;
-    __syncthreads();
-    if (w == 0 && d < D)
-      *reinterpret_cast<f32x4*>(slot + ((size_t)c * (p + 1) + j) * D + d) = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
-    __syncthreads();
   }
 }
 // (3) the marginals.  Blocks [0, p): dpos rows; [p, p + max_c): dchan rows; block p + max_c: dcls.
@@ -248,15 +263,13 @@ extern "C" int chadavit_tokenizer_bwd(const chada_bf16* dtok_, const int* cu_seq
                                       int B, int n_chan, int p, int D, int max_channels, void* stream) {
   CHADA_ENTRY();
   if (!dtok_ || !cu_seqlens || !chan_img || !chan_idx || !dpatch_tok || !dpos || !dchan || !dcls || !workspace) return 1;
-  if (B <= 0 || n_chan <= 0 || p <= 0 || D % 8 != 0 || max_channels <= 0 || ((uintptr_t)workspace & 15) != 0) return 2;
+  if (B <= 0 || n_chan <= 0 || p <= 0 || D % 8 != 0 || D > 1024 || max_channels <= 0 || ((uintptr_t)workspace & 15) != 0) return 2;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const bf16_t* dtok = reinterpret_cast<const bf16_t*>(dtok_);
   bf16_t* dpatch = reinterpret_cast<bf16_t*>(dpatch_tok);
   const int Mp = n_chan * p;
   hipLaunchKernelGGL(tokbwd_compact_kernel, dim3(grid_for((size_t)Mp * D / 8, 8192)), dim3(256), 0, s, dtok, chan_img, dpatch,
                      Mp, p, D);
-  // a (patch position, channel slot) block lists the channel instances of ITS slot: at most one per image
-  if (B > TOKB_MAXLIST) return 2;
   hipLaunchKernelGGL(tokbwd_slot_kernel, dim3(p + 1, max_channels), dim3(256), 0, s, dtok, cu_seqlens, chan_img, chan_idx, workspace, B,
                      n_chan, p, D, max_channels);
   hipLaunchKernelGGL(tokbwd_finish_kernel, dim3(p + max_channels + 1), dim3(256), 0, s, workspace, dpos, dchan, dcls, p, max_channels, D);

@@ -796,3 +796,32 @@ def test_layernorm_fwd_emits_fp8_operand(T, D):
     r2q, r2s = ops.mx8_quantize(a2)
     b1, b2, (q2, s2) = ops.layernorm_fwd2(x, ga, ba, gb, bb, 1e-5, 1e-5, emit_q=True)
     assert torch.equal(b1, a1) and torch.equal(b2, a2) and torch.equal(q2, r2q) and torch.equal(s2, r2s)
+
+
+def test_tokenizer_bwd_more_images_than_one_list_window():
+    """Tokenizer backward reductions with more sequences than one 4096-row list window (the CLS share and every channel slot go through
+    in windows): against plain torch sums over the packed gradient rows."""
+    from chadavit_amd import ops
+    from chadavit_amd.ragged import RaggedBatch
+    dev = _dev()
+    p, D, max_c = 4, 192, 10
+    nch = [1 + (i * 7) % 3 for i in range(4500)]          # 4500 images of 1-3 channels: 4500 CLS rows, ~3000 rows in slot 1
+    rb = RaggedBatch(nch, p, dev)
+    dtok = _rand((rb.T, D), 401, 1.0).bfloat16().to(dev)
+    dpatch, dpos, dchan, dcls = ops.tokenizer_bwd(dtok, rb.cu_seqlens, rb.chan_img, rb.chan_idx, p, max_c)
+    g = dtok.float().cpu()
+    cu = rb.host_cu_seqlens
+    ref_cls = torch.zeros(D); ref_pos = torch.zeros(p + 1, D); ref_chan = torch.zeros(max_c, D)
+    for b, c in enumerate(nch):
+        r0 = cu[b]
+        ref_cls += g[r0]
+        ref_pos[0] += g[r0]
+        for k in range(c):
+            blk = g[r0 + 1 + k * p:r0 + 1 + (k + 1) * p]
+            ref_pos[1:] += blk
+            ref_chan[k] += blk.sum(0)
+    def rel(a, b):
+        return float((a.cpu().float() - b).abs().max() / b.abs().max())
+    assert rel(dcls.view(-1), ref_cls) < 1e-4
+    assert rel(dchan.view(max_c, D)[:3], ref_chan[:3]) < 1e-4 and float(dchan.view(max_c, D)[3:].abs().max()) == 0.0
+    assert rel(dpos.view(p, D), ref_pos[1:]) < 1e-4
