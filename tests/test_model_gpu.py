@@ -318,6 +318,89 @@ def test_training_step_vs_golden_and_oracle(name, fused_min_rows, dispatch):
     assert all(p.grad is None for p in model.parameters())
 
 
+@pytest.mark.parametrize("name,R_,rows,weight_dtype", [("step_tiny_multicrop", 170, 600780, "bf16"), ("step_small_mixed", 70, 274820, "bf16"),
+                                                       ("step_base_c10", 25, 127500, "bf16"), ("step_base_c10", 25, 127500, "fp8")])
+def test_bench_scale_replicated_batch_vs_golden(name, R_, rows, weight_dtype):
+    """The reference golden at BENCH SCALE through a size-independent property: a batch made of R copies of the golden's
+    images has the same DINO loss (a mean over images; the centre starts at zero), the same centre update and the same
+    gradients (means again) as the golden's own 3-image batch -- but its global-crop pass is 600 780 token rows, i.e. the
+    launch shapes, work lists and kernel dispatch of bench.py's default run (603 136 rows), not the small-M ones the
+    other step goldens exercise.  Likewise Small at cfg3's scale (274 820 rows; bench: ~278 k) and Base at cfg5's (127 500 rows;
+    bench: 125 504), the latter also on the fp8 weight path with that path's tolerances (loss abs <= 5e-2)."""
+    from chadavit_amd import ops
+    from chadavit_amd.data.channels_strategies import one_channel_collate_fn
+    from chadavit_amd.methods.dino import DINO
+    from chadavit_amd.trainer import Trainer
+    dev = _dev()
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    D, PR = int(g["D"]), int(g["P"])
+    nch = [int(c) for c in g["nch"]]
+    sizes = [int(s) for s in g["sizes"]]
+    n_large, epoch = int(g["n_large"]), int(g["epoch"])
+    sd = build_sd(D, PR)
+    cfg = _cfg(D, PR, n_large, len(sizes) - n_large, clip_grad=float(g["clip_grad"]), lr=float(g["lr"]), wd=float(g["wd"]),
+               base_tau=float(g["base_tau"]))
+    fp8 = weight_dtype == "fp8"
+    if fp8:
+        cfg.backbone.kwargs.weight_dtype = "fp8"
+    model = DINO(cfg)
+    model.load_state_dict(sd)
+    model = model.to(dev)
+    imgs = P.make_images(nch, sizes, seed=7)
+    crops_s, labels_s, ncl_s = one_channel_collate_fn(imgs)
+    crops, labels, ncl = one_channel_collate_fn(list(imgs) * R_)
+    batch = ([c.to(dev) for c in crops], labels.to(dev), ncl)
+    assert rows == sum(1 + c * 196 for c in nch) * n_large * R_
+    tr = Trainer(max_epochs=10, steps_per_epoch=int(g["max_steps"]) // 10)
+    tr.current_epoch = epoch
+    tr.attach(model)
+    model.current_epoch = epoch
+    model.on_train_epoch_start()
+    with ops.LaunchProfiler() as prof:
+        loss = model.training_step(batch, 1)
+        loss.backward()
+        model.on_after_backward()
+    summ = prof.summary()
+    # the bench's dispatch at the bench's row count: the whole-block kernel in all three passes, the fused FFN backward
+    if D <= 384:
+        n_pass = 3 if len(sizes) > n_large else 2
+        assert sum(v["launches"] for k, v in summ.items() if k[0] == "proj_ffn_ln_fwd" and k[1] == rows) == 24, list(summ.keys())
+        assert sum(v["launches"] for k, v in summ.items() if k[0] == "proj_ffn_ln_fwd") == 12 * n_pass
+        assert sum(v["launches"] for k, v in summ.items() if k[0] == "ffn_bwd_dx" and k[1] == rows) == 12
+    if fp8:
+        assert sum(v["launches"] for k, v in summ.items() if k[0] == "gemm_nt_mx8" and k[1] == rows) == 4 * 12 * 2
+        assert abs(loss.item() - float(g["loss"])) <= 5e-2, (loss.item(), float(g["loss"]))
+        named = dict(model.named_parameters())
+        tot_h = sum(named[str(n)].grad.double().norm().item() ** 2 for n in g["grad_names"]) ** 0.5
+        tot_r = float(np.sqrt((g["grad_norms"] ** 2).sum()))
+        assert abs(tot_h - tot_r) <= 0.15 * tot_r, (tot_h, tot_r)   # fp8 forward activations feed a bf16 backward
+        for key in ("backbone.norm.weight", "head.mlp.4.bias"):
+            assert _cos(named[key].grad, torch.from_numpy(g["grad::" + key])) >= 0.95, key
+        return
+    assert abs(loss.item() - float(g["loss"])) <= 2e-2, (loss.item(), float(g["loss"]))
+    loss_o, grads_o, newc_o, aux = R.training_step(sd, crops_s, ncl_s, n_large, float(g["teacher_temp"]), freeze_last_layer=epoch < 1,
+                                                   clip_grad=float(g["clip_grad"]))
+    named = dict(model.named_parameters())
+    for n in set(str(n) for n in g["none_grad_names"]):
+        assert named[n].grad is None, n
+    tot_h = tot_r = 0.0
+    worst = (1.0, None)
+    for n, gn in zip(g["grad_names"], g["grad_norms"]):
+        n = str(n)
+        gh = named[n].grad
+        assert gh is not None, n
+        tot_h += gh.double().norm().item() ** 2
+        tot_r += float(gn) ** 2
+        go = grads_o[n]
+        if float(gn) > 1e-4 * np.sqrt(go.numel()) * 1e-2:
+            c = _cos(gh, go)
+            if c < worst[0]:
+                worst = (c, n)
+    assert abs(np.sqrt(tot_h) - np.sqrt(tot_r)) <= 5e-2 * np.sqrt(tot_r), (np.sqrt(tot_h), np.sqrt(tot_r))
+    assert worst[0] >= 0.99, worst
+    np.testing.assert_allclose(model.dino_loss_func.center[0, :256].float().cpu().numpy(), g["center_new"], atol=2e-3)
+
+
 def test_validation_step_vs_golden():
     """validation_step / on_validation_epoch_end (dino.py:327-365; base.py:753-899, 1278-1436) on the HIP path against the
     reference's outputs for both cfg.ssl_val_loss settings: CLS features cosine >= 0.999, probe logits / z rel-L2 <= 3e-2,
