@@ -825,3 +825,89 @@ def test_tokenizer_bwd_more_images_than_one_list_window():
     assert rel(dcls.view(-1), ref_cls) < 1e-4
     assert rel(dchan.view(max_c, D)[:3], ref_chan[:3]) < 1e-4 and float(dchan.view(max_c, D)[3:].abs().max()) == 0.0
     assert rel(dpos.view(p, D), ref_pos[1:]) < 1e-4
+
+
+@pytest.mark.parametrize("D,M,ch,n_seq", [(192, 603136, 3, 1024), (384, 278462, 10, 142), (768, 125504, 10, 64)])
+def test_hot_kernels_at_bench_rows_equal_their_small_runs(D, M, ch, n_seq):
+    """BASELINE-size launches (cfg2 at 512 images per GPU: 603 136 token rows, 1024 sequences of 589 tokens) through a
+    size-independent property: every row / sequence is processed independently of its position, so a launch over R copies
+    of a small input must reproduce the small launch's output in every copy BIT FOR BIT -- and the small launches are the ones
+    the tests above hold against fp32 torch.  Covers the whole-block forward kernel (training instance with every output), the
+    fused FFN backward from its ReLU bits, the attention forward / backward, and (sum over rows: fp32 tolerance) the
+    weight-gradient TN GEMM at 603 136 x 192 x 2048; likewise at Small's (cfg3: 142 sequences of 1961 tokens, the D = 384 builds of the
+    kernels) and Base's (cfg5: 64 x 1961; no whole-block kernel at D = 768, attention + TN only) bench shapes."""
+    from chadavit_amd import ops
+    from chadavit_amd.ragged import RaggedBatch
+    dev = _dev()
+    FF, M0 = 2048, 1024
+    assert M == n_seq * (1 + 196 * ch)   # cfg2: 603136 = 589 * 1024 rows = 4712 blocks of 128 rows
+    rep = lambda t: t.repeat((M + M0 - 1) // M0, 1)[:M].contiguous()
+    dz0 = _rand((M0, D), 181, 1.0).bfloat16().to(dev)
+    if D <= 384:
+        a0 = _rand((M0, D), 151, 1.0).bfloat16().to(dev)
+        x0 = _rand((M0, D), 152, 1.0).bfloat16().to(dev)
+        wo = (_rand((D, D), 153, 1.0) / math.sqrt(D)).bfloat16().to(dev)
+        w1 = (_rand((FF, D), 154, 1.0) / math.sqrt(D)).bfloat16().to(dev)
+        w2 = (_rand((D, FF), 155, 1.0) / math.sqrt(FF)).bfloat16().to(dev)
+        wq = (_rand((3 * D, D), 159, 1.0) / math.sqrt(D)).bfloat16().to(dev)
+        bo, b1, b2, bq = _rand((D,), 156, 0.1).to(dev), _rand((FF,), 157, 0.1).to(dev), _rand((D,), 158, 0.1).to(dev), _rand((3 * D,), 161, 0.1).to(dev)
+        lns = [((1 + _rand((D,), 160 + i, 0.2)).to(dev), _rand((D,), 170 + i, 0.2).to(dev), 1e-5) for i in range(3)]
+        slab = torch.cat([w1.reshape(-1), w2.reshape(-1), wo.reshape(-1), wq.reshape(-1)])
+        pkq = torch.empty(ops.ffn_proj_packed_bytes(D, FF) // 2, device=dev, dtype=torch.bfloat16)
+        o1, o2 = w1.numel(), w1.numel() + w2.numel()
+        ops.ffn_pack_proj_batched(slab, pkq, torch.tensor([0, o1, o2, o2 + wo.numel(), 0], device=dev, dtype=torch.int64), 1, D, FF)
+
+        def block(a, x):
+            m = a.shape[0]
+            e = lambda *s: torch.empty(s, device=dev, dtype=torch.bfloat16)
+            st = [(torch.empty(m, device=dev), torch.empty(m, device=dev)) for _ in range(3)]
+            y, z, h, bits = e(m, D), e(m, D), e(m, FF), ops.relu_bits_buffer(m, FF, dev)
+            x1, x2, hn, qkv = ops.proj_ffn_ln_fwd(a, x, pkq, bo, lns[0], b1, b2, lns[1], y=y, stats1=st[0], z=z, h=h, ln_b=lns[2],
+                                                  stats_a=st[1], stats_b=st[2], qkv_bias=bq, want_hn=True, relu_bits=bits)
+            return dict(x1=x1, x2=x2, hn=hn, qkv=qkv, y=y, z=z, h=h, m1=st[0][0], r1=st[0][1], ma=st[1][0], ra=st[1][1], mb=st[2][0],
+                        rb=st[2][1]), bits
+
+        small, bits0 = block(a0, x0)
+        big, bits = block(rep(a0), rep(x0))
+        for k, v in big.items():
+            ref = rep(small[k]) if small[k].dim() == 2 else small[k].repeat((M + M0 - 1) // M0)[:M]
+            assert torch.equal(v, ref), k
+        del big
+        # fused FFN backward from the bits the big launch recorded
+        pkb = ops.ffn_pack(w2.t().contiguous(), w1.t().contiguous())
+        dpre0 = torch.empty((M0, FF), device=dev, dtype=torch.bfloat16)
+        dx0 = ops.ffn_bwd_dx(dz0, pkb, bits0, dpre=dpre0)
+        dpre = torch.empty((M, FF), device=dev, dtype=torch.bfloat16)
+        dx = ops.ffn_bwd_dx(rep(dz0), pkb, bits, dpre=dpre)
+        assert torch.equal(dx, rep(dx0)) and torch.equal(dpre, rep(dpre0))
+    else:
+        dpre0 = _rand((M0, FF), 182, 1.0).bfloat16().to(dev)
+        dpre = rep(dpre0)
+    # weight-gradient TN GEMM over all rows: (M / M0) x the small product (fp32 partial sums in another order)
+    ws = torch.empty(24 * 1024 * 1024, device=dev)   # the backbone's own split-T workspace size
+    c_big = torch.zeros((D, FF), device=dev)
+    c_small = torch.zeros((D, FF), device=dev)
+    cs_big, cs_small = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+    ops.gemm_tn(rep(dz0), dpre, c_big, colsum=cs_big, workspace=ws)
+    ops.gemm_tn(dz0, dpre0, c_small, colsum=cs_small, workspace=ws)
+    c_ref, cs_ref = (M // M0) * c_small, (M // M0) * cs_small
+    if M % M0:   # the partial last copy
+        c_t, cs_t = torch.zeros((D, FF), device=dev), torch.zeros(D, device=dev)
+        ops.gemm_tn(dz0[:M % M0].contiguous(), dpre0[:M % M0].contiguous(), c_t, colsum=cs_t, workspace=ws)
+        c_ref, cs_ref = c_ref + c_t, cs_ref + cs_t
+    assert float((c_big - c_ref).norm() / c_ref.norm()) < 1e-4
+    assert float((cs_big - cs_ref).norm() / cs_ref.norm()) < 1e-4
+    del dpre, c_big
+    # attention: n_seq copies of one sequence (cfg2: 1024 x 589 tokens, 2 heads of 96)
+    rb1, rbn = RaggedBatch([ch], 196, dev), RaggedBatch([ch] * n_seq, 196, dev)
+    assert rbn.T == M
+    n1 = 1 + 196 * ch
+    q0 = _rand((n1, 3 * D), 191, 1.0).bfloat16().to(dev)
+    do0 = _rand((n1, D), 192, 1.0).bfloat16().to(dev)
+    out0, lse0 = ops.attn_fwd(q0, rb1.cu_seqlens, rb1.work, 2)
+    dq0 = ops.attn_bwd(q0, out0, do0, lse0, rb1.cu_seqlens, rb1.work, 2)
+    qn, don = q0.repeat(n_seq, 1), do0.repeat(n_seq, 1)
+    outn, lsen = ops.attn_fwd(qn, rbn.cu_seqlens, rbn.work, 2)
+    dqn = ops.attn_bwd(qn, outn, don, lsen, rbn.cu_seqlens, rbn.work, 2)
+    assert torch.equal(outn, out0.repeat(n_seq, 1)) and torch.equal(lsen, lse0.repeat(1, n_seq))
+    assert torch.equal(dqn, dq0.repeat(n_seq, 1))
