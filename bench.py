@@ -470,7 +470,13 @@ def main():
         nch = channel_list(wl["channels"], B, seed=1000 + rank)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     sizes = [224] * wl["n_global"] + [96] * wl["n_local"]
-    crops = [torch.randn((sum(nch), 1, s, s), device=dev, generator=gen) for s in sizes]
+    # crops of one resolution lie back to back in one buffer, as the collate (data/channels_strategies.py) and the device
+    # augmentation pipeline emit them: training_step then takes "all global crops" as a view instead of a torch.cat copy
+    crops = []
+    for s, n in ((224, wl["n_global"]), (96, wl["n_local"])):
+        if n:
+            buf = torch.randn((n * sum(nch), 1, s, s), device=dev, generator=gen)
+            crops += list(buf.chunk(n))
     labels = torch.zeros(B, dtype=torch.int64, device=dev)
     batch = (crops if len(crops) > 1 else crops[0], labels, [list(nch) for _ in sizes])
 

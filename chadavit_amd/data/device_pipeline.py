@@ -164,18 +164,22 @@ class DeviceMultiCropPipeline:
         src = host.to(self.device, non_blocking=True)
         crops, used = [], []
         it = iter(params) if params is not None else None
+        nchan = sum(nch)
         for spec in self.specs:
-            for _ in range(spec.num_crops):
+            # the crops of one spec (one resolution) go back to back into ONE buffer: DINO.training_step takes "all global
+            # crops" / "all local crops" as a view of it (channels_strategies.adjacent_view) instead of a torch.cat copy
+            buf = torch.empty((spec.num_crops * nchan, 1, spec.crop_size, spec.crop_size), device=self.device, dtype=torch.float32)
+            for k in range(spec.num_crops):
                 cp = next(it) if it is not None else self._draw(spec, shapes)
                 used.append(cp)
-                crops.append(self._run_crop(spec, cp, src, shapes, offs))
+                crops.append(self._run_crop(spec, cp, src, shapes, offs, out=buf[k * nchan:(k + 1) * nchan]))
         self.last_params = used
         lab = torch.as_tensor(list(labels) if labels is not None else [-1] * len(planes), dtype=torch.int64, device=self.device)
         if len(crops) == 1:   # one_channel_collate_fn returns a bare tensor / list for a single crop (channels_strategies.py:81)
             return crops[0], lab, nch
         return crops, lab, [list(nch) for _ in crops]
 
-    def _run_crop(self, spec: CropSpec, cp: CropParams, src, shapes, offs) -> torch.Tensor:
+    def _run_crop(self, spec: CropSpec, cp: CropParams, src, shapes, offs, out=None) -> torch.Tensor:
         S = spec.crop_size
         desc, shift, gamma, fin = [], [], [], []
         any_jit = any(s is not None for s in cp.shifts)
@@ -206,10 +210,12 @@ class DeviceMultiCropPipeline:
                     fin.append(row)
         dev = self.device
         d = torch.tensor(desc, dtype=torch.int64).to(dev)
+        first = None if any_fin else out   # the finishing pass reads the resized planes and writes the caller's buffer
         if any_jit:   # gamma = -1 marks the channel images whose sample did not draw the jitter (no clamp for them)
-            out = ops.crop_resize(src, d, S, torch.tensor(shift, dtype=torch.float32).to(dev), torch.tensor(gamma, dtype=torch.float32).to(dev))
+            res = ops.crop_resize(src, d, S, torch.tensor(shift, dtype=torch.float32).to(dev), torch.tensor(gamma, dtype=torch.float32).to(dev),
+                                  out=first)
         else:
-            out = ops.crop_resize(src, d, S)
+            res = ops.crop_resize(src, d, S, out=first)
         if any_fin:
-            out = ops.blur_finish(out, torch.from_numpy(np.stack(fin)).to(dev))
-        return out
+            res = ops.blur_finish(res, torch.from_numpy(np.stack(fin)).to(dev), out=out)
+        return res

@@ -25,6 +25,7 @@ import torch.nn as nn
 from .. import ops
 from ..backbones import vit_channels
 from ..backbones.vit.chada_vit import ChAdaViT, trunc_normal_
+from ..data.channels_strategies import adjacent_view
 from ..flat import FlatParams
 from ..losses.dino import DINOLoss
 from ..utils.misc import AttrDict, ensure_node, is_missing, omegaconf_select
@@ -414,7 +415,9 @@ class DINO(_Base):
                 self._streams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
             s_teacher, s_local = self._streams
         if self.batch_crops and same_size:
-            xg = torch.cat(list(X[:nl]), dim=0)
+            xg = adjacent_view(list(X[:nl]))   # crops written back to back by the collate / augmentation: no copy
+            if xg is None:
+                xg = torch.cat(list(X[:nl]), dim=0)
             nch = [c for k in range(nl) for c in list_num_channels[k]]
             if use_streams:
                 # after the cat above (and after the previous step's optimiser / EMA, all enqueued on `main`)
@@ -443,7 +446,9 @@ class DINO(_Base):
             ctx = torch.cuda.stream(s_local) if use_streams else torch.no_grad()
             with ctx, torch.no_grad():
                 if self.batch_crops and all(x.shape[-1] == small[0].shape[-1] for x in small):
-                    xs = torch.cat(small, dim=0)
+                    xs = adjacent_view(small)
+                    if xs is None:
+                        xs = torch.cat(small, dim=0)
                     nchs = [c for k in range(len(small)) for c in list_num_channels[nl + k]]
                     feats_list += list(self.backbone.forward_ragged(xs, nchs).chunk(len(small)))
                 else:

@@ -81,3 +81,9 @@ def test_pipeline_feeds_the_training_step():
     tr = Trainer(max_epochs=2, steps_per_epoch=4).attach(model)
     losses = [tr.train_step(pipe(_batch(s)), s).item() for s in range(2)]
     assert all(np.isfinite(losses)) and abs(losses[0] - np.log(4096)) < 1.0, losses
+    # the crops of one resolution leave the pipeline back to back in one buffer: the step takes them as a view, not a cat copy
+    from chadavit_amd.data.channels_strategies import adjacent_view
+    crops, _, _ = pipe(_batch(5))
+    g, l = adjacent_view(crops[:2]), adjacent_view(crops[2:])
+    assert g is not None and l is not None and g.data_ptr() == crops[0].data_ptr()
+    assert torch.equal(g, torch.cat(crops[:2])) and torch.equal(l, torch.cat(crops[2:]))

@@ -106,6 +106,25 @@ def test_collate_matches_oracle():
     assert isinstance(a1, torch.Tensor) and a1.shape == (8, 1, 32, 32) and n1 == [[2, 5, 1]]
 
 
+def test_collate_groups_equal_resolutions_into_one_buffer():
+    """Crops of one resolution leave the collate back to back in one buffer (same tensors as the reference's collate), so the
+    training step can take "all global crops" as a view: adjacent_view == torch.cat without the copy, None when it cannot."""
+    from chadavit_amd.data.channels_strategies import adjacent_view, one_channel_collate_fn
+    from oracle import chada_ref as R
+    from oracle import procedural as P
+    imgs = P.make_images([2, 5, 1], [32, 32, 16, 16, 16], seed=2)
+    a, _, na = one_channel_collate_fn(imgs)
+    b, _, nb = R.collate(imgs)
+    assert na == nb and all(torch.equal(x, y) for x, y in zip(a, b))
+    g, l = adjacent_view(a[:2]), adjacent_view(a[2:])
+    assert g is not None and l is not None
+    assert torch.equal(g, torch.cat(a[:2])) and torch.equal(l, torch.cat(a[2:]))
+    assert g.data_ptr() == a[0].data_ptr() and l.data_ptr() == a[2].data_ptr()   # views, not copies
+    assert adjacent_view([a[1], a[0]]) is None and adjacent_view([a[0], a[2]]) is None
+    assert adjacent_view([t.clone() for t in a[:2]]) is None
+    assert adjacent_view([a[0][:, :, ::2]]) is None
+
+
 def test_schedules_and_optimizer_host_logic():
     import numpy as np
     from chadavit_amd.optim import WarmupCosineLR
