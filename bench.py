@@ -557,7 +557,15 @@ def main():
             summ = prof_summary
             tot_ms = sum(v["total_ms"] for v in summ.values())
             key = max(summ, key=lambda k: summ[k]["total_ms"])
-            st = summ[key]
+            st = dict(summ[key])
+            # the dominant kernel's duration for the roofline: its launches timed INSIDE ordinary training steps (HIP events on the
+            # launch stream) -- that is what rocprofv3 --kernel-trace of this command reports for it too (profiles/: within 2 %).
+            # The back-to-back replay of one kernel on fresh random operands runs hotter (the part's power budget)
+            # and reads up to 10 % longer; it stays in the line as avg_us_replay.  With side streams on, the in-step figure
+            # includes CU sharing with the kernels beside it, and the replay remains the reference.
+            st["replay_avg_us"] = st["avg_us"]
+            if "in_step_avg_us" in st and not model.backbone.dw_side_stream:
+                st["avg_us"] = st["in_step_avg_us"]
             sumsq = {}
             p224, p96 = 196, 36
             tg = sum(1 + c * p224 for c in nch) * wl["n_global"]
@@ -627,7 +635,8 @@ def main():
             except OSError:
                 pass
             roof.update({"kernel": "/".join(str(k) for k in key), "avg_us": round(st["avg_us"], 2),
-                         "avg_us_in_step": round(st.get("in_step_avg_us", float("nan")), 2), "streams": "overlapped" if model.backbone.dw_side_stream else "serial",
+                         "avg_us_in_step": round(st.get("in_step_avg_us", float("nan")), 2), "avg_us_replay": round(st["replay_avg_us"], 2),
+                         "streams": "overlapped" if model.backbone.dw_side_stream else "serial",
                          "launches_per_step": st["launches"],
                          "share_of_instrumented_gpu_time": round(st["total_ms"] / tot_ms, 4),
                          "instrumented_ms_per_step": round(tot_ms, 3)})
