@@ -461,6 +461,35 @@ def attn_fwd(qkv, cu, work, H, out=None, lse=None):
     return out, lse
 
 
+@_timed(lambda qkv, cu, H, *a, **k: ("attn_cls_fwd", qkv.shape[0], qkv.shape[1] // 3, H, cu.shape[0] - 1))
+def attn_cls_fwd(qkv, cu, H):
+    """Attention of the CLS row (first row) of every sequence against all keys of its sequence: (out_cls [B, D] bf16, lse_cls [H, B])."""
+    _req(qkv, BF16, "qkv"); _req(cu, I32, "cu")
+    T, D3 = qkv.shape
+    D, B = D3 // 3, cu.shape[0] - 1
+    out = torch.empty((B, D), device=qkv.device, dtype=BF16)
+    lse = torch.empty((H, B), device=qkv.device, dtype=F32)
+    rc = lib().chadavit_attn_cls_fwd(_ptr(qkv), _ptr(cu), _ptr(out), _ptr(lse), c_int(B), c_int(D), c_int(H),
+                                     c_float(float(D // H) ** -0.5), _stream())
+    _chk(rc, "chadavit_attn_cls_fwd")
+    return out, lse
+
+
+@_timed(lambda qkv, cu, out_cls, dout_cls, lse_cls, H, *a, **k: ("attn_cls_bwd", qkv.shape[0], qkv.shape[1] // 3, H, cu.shape[0] - 1))
+def attn_cls_bwd(qkv, cu, out_cls, dout_cls, lse_cls, H, dqkv=None):
+    """dqkv [T, 3D] (every element written) for a loss that reads only the CLS rows of the attention output."""
+    _req(qkv, BF16, "qkv"); _req(cu, I32, "cu"); _req(out_cls, BF16, "out_cls"); _req(dout_cls, BF16, "dout_cls"); _req(lse_cls, F32, "lse_cls")
+    T, D3 = qkv.shape
+    D, B = D3 // 3, cu.shape[0] - 1
+    if dqkv is None:
+        dqkv = torch.empty_like(qkv)
+    _req(dqkv, BF16, "dqkv")
+    rc = lib().chadavit_attn_cls_bwd(_ptr(qkv), _ptr(cu), _ptr(out_cls), _ptr(dout_cls), _ptr(lse_cls), _ptr(dqkv), c_int(B), c_int(D),
+                                     c_int(H), c_float(float(D // H) ** -0.5), _stream())
+    _chk(rc, "chadavit_attn_cls_bwd")
+    return dqkv
+
+
 @_timed(lambda qkv, out, dout, lse, cu, work, H, *a, **k: ("attn_bwd", qkv.shape[0], qkv.shape[1] // 3, H, work.shape[0]))
 def attn_bwd(qkv, out, dout, lse, cu, work, H, dqkv=None, delta=None, side=None):
     """dqkv from dout.  With `side` (a HIP stream) the dK/dV kernel runs there while dQ runs on the current stream

@@ -128,6 +128,16 @@ int chadavit_layernorm_bwd_pair(const chada_bf16* dy, const chada_bf16* x, const
  * --------------------------------------------------------------------------------------------- */
 int chadavit_attn_fwd(const chada_bf16* qkv, chada_bf16* out, float* lse, const int* cu_seqlens, const int* work,
                       int n_work, int T, int D, int H, void* stream);
+
+/* Attention of ONE query row per sequence -- the CLS row (first row of each sequence) -- against all keys of its sequence.
+ * With return_all_tokens = False (args/pretrain.py:147) only norm(x)[:, 0] leaves ChAdaViT.forward (chada_vit.py:272-289): of the
+ * last encoder block's attention (chada_vit.py:105-111) only that row is ever read.  out_cls [B, D] bf16; lse_cls [H, B] fp32.
+ * _bwd: gradients of autograd when only the CLS rows carry one: dqkv [T, 3D] is written completely (dQ = 0 off the CLS rows,
+ * dK / dV of every row = the CLS query's contribution).  scale = the softmax scale 1/sqrt(D/H); (D/H) % 8 == 0. */
+int chadavit_attn_cls_fwd(const chada_bf16* qkv, const int* cu_seqlens, chada_bf16* out_cls, float* lse_cls, int B, int D, int H,
+                          float scale, void* stream);
+int chadavit_attn_cls_bwd(const chada_bf16* qkv, const int* cu_seqlens, const chada_bf16* out_cls, const chada_bf16* dout_cls,
+                          const float* lse_cls, chada_bf16* dqkv, int B, int D, int H, float scale, void* stream);
 /* bwd: dqkv [T,3D] from dout [T,D]; delta workspace fp32 [H, T]. */
 int chadavit_attn_bwd(const chada_bf16* qkv, const chada_bf16* out, const chada_bf16* dout, const float* lse,
                       chada_bf16* dqkv, float* delta, const int* cu_seqlens, const int* work, int n_work, int T,

@@ -911,3 +911,39 @@ def test_hot_kernels_at_bench_rows_equal_their_small_runs(D, M, ch, n_seq):
     dqn = ops.attn_bwd(qn, outn, don, lsen, rbn.cu_seqlens, rbn.work, 2)
     assert torch.equal(outn, out0.repeat(n_seq, 1)) and torch.equal(lsen, lse0.repeat(1, n_seq))
     assert torch.equal(dqn, dq0.repeat(n_seq, 1))
+
+
+@pytest.mark.parametrize("nch,p,D,H", [([3, 1, 10, 5], 196, 192, 2), ([1, 2], 36, 192, 2), ([2, 1, 1], 36, 384, 2), ([1], 4, 64, 2),
+                                       ([3, 2], 36, 128, 2), ([2, 1], 36, 768, 2), ([1, 10], 196, 768, 2), ([2, 3], 36, 192, 12),
+                                       ([1] * 70, 1, 192, 2)])
+def test_attention_of_the_cls_rows(nch, p, D, H):
+    """chadavit_attn_cls_fwd / _bwd against fp32 torch attention over all rows: the CLS rows of the output, and the gradient of a loss
+    that reads only those rows (dQ exactly zero elsewhere, dK / dV of every row), and against the flash kernels' CLS rows."""
+    from chadavit_amd import ops
+    from chadavit_amd.ragged import RaggedBatch
+    dev = _dev()
+    rb = RaggedBatch(nch, p, dev)
+    T = rb.T
+    cls = rb.cls_rows.long()
+    qkv = _rand((T, 3 * D), 12, 1.0).bfloat16().to(dev)
+    qkv[0, :D] *= 4.0   # a peaky softmax for the first image's CLS query
+    dout_cls = _rand((len(nch), D), 13, 1.0).bfloat16().to(dev)
+    out_cls, lse_cls = ops.attn_cls_fwd(qkv, rb.cu_seqlens, H)
+    qf = qkv.float().requires_grad_(True)
+    ref = _attn_ref(qf, rb.host_cu_seqlens, H)
+    _close(out_cls, ref[cls], 1e-2, 1e-2, "attn cls fwd")
+    full, lse_full = ops.attn_fwd(qkv, rb.cu_seqlens, rb.work, H)
+    _close(out_cls, full[cls].float(), 2e-2, 2e-2, "attn cls fwd vs flash")
+    assert torch.allclose(lse_cls, lse_full[:, cls], atol=2e-2)
+    dfull = torch.zeros((T, D), device=dev)
+    dfull[cls] = dout_cls.float()
+    ref.backward(dfull)
+    dqkv = ops.attn_cls_bwd(qkv, rb.cu_seqlens, out_cls, dout_cls, lse_cls, H)
+    g = qf.grad
+    scale = g.abs().max().item()
+    _close(dqkv[:, 2 * D:], g[:, 2 * D:], 2e-2, 2e-2 * scale, "dV")
+    _close(dqkv[:, D:2 * D], g[:, D:2 * D], 2e-2, 2e-2 * scale, "dK")
+    _close(dqkv[cls, :D], g[cls, :D], 2e-2, 2e-2 * scale, "dQ cls")
+    notcls = torch.ones(T, dtype=torch.bool, device=dev)
+    notcls[cls] = False
+    assert float(dqkv[notcls, :D].float().abs().max()) == 0.0 if notcls.any() else True
