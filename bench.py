@@ -77,22 +77,27 @@ def parse():
 
 
 # ---- algorithmic FLOPs (ragged, padding-free) ---------------------------------------
-def f_backbone(C, S, D, ffn=2048, depth=12, patch=16):
+def f_backbone(C, S, D, ffn=2048, depth=12, patch=16, cls_last=False):
+    """cls_last: the last block as the build executes it with return_all_tokens = False (ChAdaViT.cls_only_last_block): K / V / Q
+    projections on all rows, then one query row per image through attention, out-proj and the FFN."""
     p = (S // patch) ** 2
     N = 1 + C * p
-    return 2 * C * p * patch * patch * D + depth * (8 * N * D * D + 4 * N * N * D + 4 * N * D * ffn)
+    block = 8 * N * D * D + 4 * N * N * D + 4 * N * D * ffn
+    last = (6 * N * D * D + 4 * N * D + 2 * D * D + 4 * D * ffn) if cls_last else block
+    return 2 * C * p * patch * patch * D + (depth - 1) * block + last
 
 
 def f_head(D, P, hidden=2048, bott=256):
     return 2 * (D * hidden + hidden * hidden + hidden * bott + bott * P)
 
 
-def gflop_per_image(channels, D, P, n_global, n_local):
-    """mean over the channel distribution of: 2*3*F_fwd(224) + 2*F_fwd(224) + n_local*F_bb(96) (parity semantics)."""
+def gflop_per_image(channels, D, P, n_global, n_local, cls_last=False):
+    """mean over the channel distribution of: 2*3*F_fwd(224) + 2*F_fwd(224) + n_local*F_bb(96) (parity semantics).
+    cls_last=False: the reference's algorithm (every row through every block); True: what this build executes."""
     tot = 0.0
     for C in channels:
-        ffwd = f_backbone(C, 224, D) + f_head(D, P)
-        tot += n_global * 3 * ffwd + n_global * ffwd + n_local * f_backbone(C, 96, D)
+        ffwd = f_backbone(C, 224, D, cls_last=cls_last) + f_head(D, P)
+        tot += n_global * 3 * ffwd + n_global * ffwd + n_local * f_backbone(C, 96, D, cls_last=cls_last)
     return tot / len(channels) / 1e9
 
 
@@ -538,7 +543,11 @@ def main():
         value = B * world * args.steps / dt
         chans = sorted(set(nch)) if "-" not in wl["channels"] else list(range(1, 11))
         gf_img = gflop_per_image(chans if "-" in wl["channels"] else [int(wl["channels"])], wl["D"], wl["P"], wl["n_global"], wl["n_local"])
-        step_tflops = value * gf_img / 1e3 / world
+        # utilisation is priced with the FLOPs the build EXECUTES: with return_all_tokens = False its last block runs on the CLS rows
+        # only (same outputs and gradients as the reference's full-width block)
+        gf_exec = gflop_per_image(chans if "-" in wl["channels"] else [int(wl["channels"])], wl["D"], wl["P"], wl["n_global"], wl["n_local"],
+                                  cls_last=bool(model.backbone.cls_only_last_block))
+        step_tflops = value * gf_exec / 1e3 / world
         out = {
             "metric": "images/sec ChAda-ViT DINO multi-crop pretrain (whole training step)",
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -548,7 +557,8 @@ def main():
             "config": {"workload": f"{args.workload}: {wl['desc']}, bf16 storage / fp32 accumulate, {B} images per GPU, "
                                    f"head 2048/256/{wl['P']}, AdamW, reference-parity crop semantics",
                        "global_batch": B * world, "parallelism": f"dp{world}", "final_loss": round(loss_val, 4),
-                       "algorithmic_gflop_per_image": round(gf_img, 1), "achieved_tflops_per_gpu": round(step_tflops, 1),
+                       "algorithmic_gflop_per_image": round(gf_img, 1), "executed_gflop_per_image": round(gf_exec, 1),
+                       "achieved_tflops_per_gpu": round(step_tflops, 1),
                        "mfma_fraction_whole_step": round(step_tflops / PEAK_BF16_TFLOPS, 4)},
         }
         # ---- roofline of the dominant instrumented kernel, from live HIP-event timings

@@ -118,6 +118,11 @@ class ChAdaViT(nn.Module):
         # MFMA -- weights AND their input activations quantised to OCP-MX e4m3 (BASELINE.json configs[4], ChAda-ViT-Base); the
         # backward keeps bf16 operands.  Needs embed_dim % 128 == 0.
         self.weight_dtype = "bf16"
+        # return_all_tokens = False: only norm(x)[:, 0] leaves forward() (reference chada_vit.py:272-289), so of the LAST block's output only
+        # the CLS rows are ever read -- its attention output, out-projection, LayerNorms and FFN run on one row per image (K / V
+        # projections on all rows: the CLS query attends to every token).  Same CLS features and gradients; 1/12 of the encoder's
+        # row-wise work and 4/5 of that block's attention less.  (_last_block_cls_fwd / _bwd)
+        self.cls_only_last_block = not os.environ.get("CHADAVIT_FULL_LAST_BLOCK")
         self.fp8_ln_emits_operand = True  # fp8 path: LayerNorm kernels also emit the following GEMM's quantised operand (measured neutral)
         self._capture_blocks = None  # tests: {block index: None} -> filled with that block's output (packed rows) by the forward
 
@@ -384,6 +389,80 @@ def _block_fwd(m: ChAdaViT, flat: FlatParams, i: int, x, rb: RaggedBatch, save: 
     return x2, saved, h_next, st_next, qkv_next
 
 
+def _last_block_cls_fwd(m: ChAdaViT, flat: FlatParams, i: int, x, rb: RaggedBatch, save: bool, h=None, st=None, qkv=None):
+    """The last post-norm block when only its CLS rows are read (ChAdaViT.cls_only_last_block): LN1 and the QKV projection on all
+    rows (unless the previous block's kernel already produced them), attention of the CLS query per image, then out-proj +
+    residual + norm1 + FFN + norm2 on B rows.  Returns (x2 of the CLS rows [B, D], saved)."""
+    b = f"blocks.{i}."
+    T, B = x.shape[0], rb.B
+    dev = x.device
+    eps = m.blocks[i].norm1.eps
+    H = m.blocks[i].nhead
+    if st is None:
+        st = torch.empty((2, T), device=dev, dtype=torch.float32) if save else None
+    g1, b1 = flat.f(b + "norm1.weight"), flat.f(b + "norm1.bias")
+    fq = m.weight_dtype == "fp8" and x.shape[1] in ops.LN_PAIR_WIDTHS and m.fp8_ln_emits_operand
+    hq = None
+    if isinstance(h, tuple):
+        h, hq = h
+    if h is None and qkv is None:
+        if fq:
+            h, hq = ops.layernorm_fwd(x, g1, b1, eps, mean=st[0] if save else None, rstd=st[1] if save else None, emit_q=True)
+        else:
+            h = ops.layernorm_fwd(x, g1, b1, eps, mean=st[0] if save else None, rstd=st[1] if save else None)
+    if qkv is None:
+        qkv = _linear(m, flat, h, b + "self_attn.in_proj_weight", flat.f(b + "self_attn.in_proj_bias"), xq=hq)
+    a, lse = ops.attn_cls_fwd(qkv, rb.cu_seqlens, H)
+    xc = ops.gather_rows(x, rb.cls_rows)
+    stc = torch.empty((4, B), device=dev, dtype=torch.float32) if save else None
+    y = _linear(m, flat, a, b + "self_attn.out_proj.weight", flat.f(b + "self_attn.out_proj.bias"), ops.EPI_RESID, xc)
+    ln2 = (flat.f(b + "norm2.weight"), flat.f(b + "norm2.bias"), m.blocks[i].norm2.eps)
+    if fq:
+        x1, x1q = ops.layernorm_fwd(y, g1, b1, eps, mean=stc[0] if save else None, rstd=stc[1] if save else None, emit_q=True)
+        hid, hidq = _linear(m, flat, x1, b + "linear1.weight", flat.f(b + "linear1.bias"), ops.EPI_RELU, xq=x1q, emit_q=True, want_out=save)
+        z = _linear(m, flat, hid, b + "linear2.weight", flat.f(b + "linear2.bias"), ops.EPI_RESID, x1, xq=hidq)
+    else:
+        x1 = ops.layernorm_fwd(y, g1, b1, eps, mean=stc[0] if save else None, rstd=stc[1] if save else None)
+        hid = _linear(m, flat, x1, b + "linear1.weight", flat.f(b + "linear1.bias"), ops.EPI_RELU)
+        z = _linear(m, flat, hid, b + "linear2.weight", flat.f(b + "linear2.bias"), ops.EPI_RESID, x1)
+    x2 = ops.layernorm_fwd(z, ln2[0], ln2[1], ln2[2], mean=stc[2] if save else None, rstd=stc[3] if save else None)
+    saved = (x, h, qkv, a, lse, y, x1, hid, z, st, stc) if save else None
+    return x2, saved
+
+
+def _last_block_cls_bwd(m: ChAdaViT, flat: FlatParams, i: int, dx2, saved, rb: RaggedBatch, acc: bool, tn_ws, ln_ws, defer=False):
+    """Backward of _last_block_cls_fwd: dx2 [B, D] is the gradient of the CLS rows of the block's output.  The row-wise part runs on B
+    rows; the attention backward yields dK / dV for every token (and dQ on the CLS rows) from the one query row per image; from the
+    QKV projection on, everything is full-width again.  Returns what _block_bwd returns."""
+    b = f"blocks.{i}."
+    x, h, qkv, a, lse, y, x1, hid, z, st, stc = saved
+    H = m.blocks[i].nhead
+    G = flat.g
+
+    def dw(a_t, b_t, wname, bname):
+        ops.gemm_tn(a_t, b_t, G(wname), colsum=G(bname), accumulate=acc, workspace=tn_ws)
+
+    dz = ops.layernorm_bwd(dx2, z, stc[2], stc[3], flat.f(b + "norm2.weight"), G(b + "norm2.weight"), G(b + "norm2.bias"), ln_ws,
+                           accumulate=acc)
+    dhid = ops.gemm_nt(dz, flat.wt(b + "linear2.weight"), epilogue=ops.EPI_RELUMASK, aux=hid)
+    dw(dz, hid, b + "linear2.weight", b + "linear2.bias")
+    dx1 = ops.gemm_nt(dhid, flat.wt(b + "linear1.weight"), epilogue=ops.EPI_RESID, aux=dz)
+    dw(dhid, x1, b + "linear1.weight", b + "linear1.bias")
+    g1 = flat.f(b + "norm1.weight")
+    dy = ops.layernorm_bwd(dx1, y, stc[0], stc[1], g1, G(b + "norm1.weight"), G(b + "norm1.bias"), ln_ws, accumulate=acc)
+    da = ops.gemm_nt(dy, flat.wt(b + "self_attn.out_proj.weight"))
+    dw(dy, a, b + "self_attn.out_proj.weight", b + "self_attn.out_proj.bias")
+    dqkv = ops.attn_cls_bwd(qkv, rb.cu_seqlens, a, da, lse, H)
+    dh = ops.gemm_nt(dqkv, flat.wt(b + "self_attn.in_proj_weight"))
+    dw(dqkv, h, b + "self_attn.in_proj_weight", b + "self_attn.in_proj_bias")
+    dy_full = ops.scatter_rows_zero(dy, rb.cls_rows, rb.T)  # the residual branch x -> y exists on the CLS rows only
+    # norm1 is applied twice in the forward (chada_vit.py:96,99): its gradient gets both contributions
+    if defer:
+        return None, (dh, x, st[0], st[1], g1, G(b + "norm1.weight"), G(b + "norm1.bias"), dy_full)
+    dx = ops.layernorm_bwd(dh, x, st[0], st[1], g1, G(b + "norm1.weight"), G(b + "norm1.bias"), ln_ws, dres=dy_full, accumulate=True)
+    return dx, None
+
+
 def _block_bwd(m: ChAdaViT, flat: FlatParams, i: int, dx2, saved, rb: RaggedBatch, acc: bool, tn_ws, ln_ws, side=None, keep=None,
                pend=None, defer=False):
     """acc: gradients of this backward call are ADDED to what the flat grad buffer already holds.
@@ -453,7 +532,14 @@ class _BackboneFn(torch.autograd.Function):
         tok, patches = _tokenize(m, flat, x, rb, pos_c, add_chan)
         saved_blocks = []
         xcur, hcur, stcur, qcur = tok, None, None, None
+        L = len(m.blocks) - 1
+        cls_last = (m.cls_only_last_block and not m.return_all_tokens
+                    and not (m._capture_blocks is not None and L in m._capture_blocks))
         for i in range(len(m.blocks)):
+            if i == L and cls_last:
+                xcur, sv = _last_block_cls_fwd(m, flat, i, xcur, rb, need_grad, h=hcur, st=stcur, qkv=qcur)
+                saved_blocks.append(sv)
+                break
             xcur, sv, hcur, stcur, qcur = _block_fwd(m, flat, i, xcur, rb, need_grad, h=hcur, st=stcur, qkv=qcur)
             saved_blocks.append(sv)
             if m._capture_blocks is not None and i in m._capture_blocks:
@@ -468,12 +554,13 @@ class _BackboneFn(torch.autograd.Function):
             ctx.mode = "all"
             ctx.final = (xcur, st, keep) if need_grad else None
         else:
-            xc = ops.gather_rows(xcur, rb.cls_rows)
+            xc = xcur if cls_last else ops.gather_rows(xcur, rb.cls_rows)   # (cls_last: the last block already ran on the CLS rows)
             st = torch.empty((2, rb.B), device=x.device, dtype=torch.float32)
             fc = ops.layernorm_fwd(xc, gn, bn, m.norm.eps, mean=st[0], rstd=st[1])
             out = fc.float()
             ctx.mode = "cls"
             ctx.final = (xc, st)
+        ctx.cls_last = cls_last
         ctx.m, ctx.rb, ctx.add_chan, ctx.need_grad = m, rb, add_chan, need_grad
         ctx.saved_blocks = saved_blocks if need_grad else None
         ctx.patches = patches if need_grad else None
@@ -504,7 +591,7 @@ class _BackboneFn(torch.autograd.Function):
             xc, st = ctx.final
             dxc = ops.layernorm_bwd(dout.to(torch.bfloat16).contiguous(), xc, st[0], st[1], flat.f("norm.weight"), G("norm.weight"),
                                     G("norm.bias"), ln_ws, accumulate=acc)
-            dx = ops.scatter_rows_zero(dxc, rb.cls_rows, rb.T)
+            dx = dxc if ctx.cls_last else ops.scatter_rows_zero(dxc, rb.cls_rows, rb.T)
         else:  # all patch tokens returned (chada_vit.py:283-287): the CLS rows of the final LayerNorm get no gradient
             xlast, st, keep = ctx.final
             dfull = torch.zeros((rb.T, D), device=dev, dtype=torch.bfloat16)
@@ -526,7 +613,10 @@ class _BackboneFn(torch.autograd.Function):
         pend = None
         for i in reversed(range(len(m.blocks))):
             defer = pair and i > 0
-            dx, new_pend = _block_bwd(m, flat, i, dx, ctx.saved_blocks[i], rb, acc, tn_ws, ln_ws, side, keep, pend=pend, defer=defer)
+            if ctx.cls_last and i == len(m.blocks) - 1:
+                dx, new_pend = _last_block_cls_bwd(m, flat, i, dx, ctx.saved_blocks[i], rb, acc, tn_ws, ln_ws, defer=defer)
+            else:
+                dx, new_pend = _block_bwd(m, flat, i, dx, ctx.saved_blocks[i], rb, acc, tn_ws, ln_ws, side, keep, pend=pend, defer=defer)
             ctx.saved_blocks[i] = None
             if side is not None and (hook is not None or (i % 3) == 0):
                 main.wait_stream(side)  # weight gradients of the blocks so far are final; their operands may be released

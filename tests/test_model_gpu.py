@@ -203,11 +203,13 @@ def _assert_block_kernel_dispatch(summary, D, expect_fused):
     outproj = [v["launches"] for k, v in summary.items()
                if k[0] == "gemm_nt" and k[2] == D and k[3] == D and k[4] == ops.EPI_RESID]
     ln2 = [v["launches"] for k, v in summary.items() if k[0] == "layernorm_fwd2"]
+    # (the LAST block runs on the CLS rows only -- ChAdaViT.cls_only_last_block -- as a GEMM + LayerNorm chain on B rows: 11 whole-block
+    # launches per pass and one small out-proj GEMM)
     if expect_fused == "all":
-        assert sum(blk) >= 24 and sum(blk) % 12 == 0, summary.keys()   # 12 per backbone pass (student, teacher[, local])
-        assert not outproj and not ln2, (outproj, ln2)
+        assert sum(blk) >= 22 and sum(blk) % 11 == 0, summary.keys()   # 11 per backbone pass (student, teacher[, local])
+        assert sum(outproj) == sum(blk) // 11 and not ln2, (outproj, ln2)
     elif expect_fused == "global":  # the global-crop passes are above the row threshold, the local-crop pass below it
-        assert sum(blk) == 24 and sum(outproj) == 12 and sum(ln2) == 11, (blk, outproj, ln2)
+        assert sum(blk) == 22 and sum(outproj) == 12 + 2 and sum(ln2) == 11, (blk, outproj, ln2)
     else:
         assert not blk and sum(outproj) >= 24, (blk, outproj)
 
@@ -260,13 +262,15 @@ def test_training_step_vs_golden_and_oracle(name, fused_min_rows, dispatch):
         _assert_block_kernel_dispatch(prof.summary(), D, dispatch)
     elif dispatch == "small_fused":  # D = 384: the whole-block forward kernel (8 waves x 16 rows) and the fused backward dX pass
         summ = prof.summary()
-        assert sum(v["launches"] for k, v in summ.items() if k[0] == "proj_ffn_ln_fwd") == 36   # student, teacher, local passes
+        # student, teacher, local passes; the last block of each runs on its CLS rows as a GEMM chain (cls_only_last_block)
+        assert sum(v["launches"] for k, v in summ.items() if k[0] == "proj_ffn_ln_fwd") == 33
         assert not [k for k in summ if k[0] == "ffn_ln_fwd"]
-        # the next block's QKV rides in the kernel: one stand-alone in_proj GEMM per pass (block 0), no stand-alone out-proj
+        # the next block's QKV rides in the kernel: one stand-alone in_proj GEMM per pass (block 0); stand-alone out-proj / linear1
+        # only for the last block's CLS rows
         assert sum(v["launches"] for k, v in summ.items() if k[0] == "gemm_nt" and k[2] == 3 * D and k[3] == D) == 3
-        assert not [k for k in summ if k[0] == "gemm_nt" and k[2] == D and k[3] == D and k[4] == ops.EPI_RESID]
-        assert sum(v["launches"] for k, v in summ.items() if k[0] == "ffn_bwd_dx") == 12
-        assert not [k for k in summ if k[0] == "gemm_nt" and k[2] == 2048 and k[3] == D and k[4] == ops.EPI_RELU]  # no stand-alone linear1
+        assert sum(v["launches"] for k, v in summ.items() if k[0] == "gemm_nt" and k[2] == D and k[3] == D and k[4] == ops.EPI_RESID) == 3
+        assert sum(v["launches"] for k, v in summ.items() if k[0] == "ffn_bwd_dx") == 11
+        assert sum(v["launches"] for k, v in summ.items() if k[0] == "gemm_nt" and k[2] == 2048 and k[3] == D and k[4] == ops.EPI_RELU) == 3
     # ---- loss
     assert abs(loss.item() - float(g["loss"])) <= 2e-2, (loss.item(), float(g["loss"]))
     # ---- gradients vs golden norms and vs oracle tensors
@@ -364,11 +368,14 @@ def test_bench_scale_replicated_batch_vs_golden(name, R_, rows, weight_dtype):
     # the bench's dispatch at the bench's row count: the whole-block kernel in all three passes, the fused FFN backward
     if D <= 384:
         n_pass = 3 if len(sizes) > n_large else 2
-        assert sum(v["launches"] for k, v in summ.items() if k[0] == "proj_ffn_ln_fwd" and k[1] == rows) == 24, list(summ.keys())
-        assert sum(v["launches"] for k, v in summ.items() if k[0] == "proj_ffn_ln_fwd") == 12 * n_pass
-        assert sum(v["launches"] for k, v in summ.items() if k[0] == "ffn_bwd_dx" and k[1] == rows) == 12
+        # (11 of the 12 blocks: the last one runs on the CLS rows, ChAdaViT.cls_only_last_block)
+        assert sum(v["launches"] for k, v in summ.items() if k[0] == "proj_ffn_ln_fwd" and k[1] == rows) == 22, list(summ.keys())
+        assert sum(v["launches"] for k, v in summ.items() if k[0] == "proj_ffn_ln_fwd") == 11 * n_pass
+        assert sum(v["launches"] for k, v in summ.items() if k[0] == "ffn_bwd_dx" and k[1] == rows) == 11
+        assert sum(v["launches"] for k, v in summ.items() if k[0] == "attn_cls_fwd" and k[1] == rows) == 2
+        assert sum(v["launches"] for k, v in summ.items() if k[0] == "attn_cls_bwd" and k[1] == rows) == 1
     if fp8:
-        assert sum(v["launches"] for k, v in summ.items() if k[0] == "gemm_nt_mx8" and k[1] == rows) == 4 * 12 * 2
+        assert sum(v["launches"] for k, v in summ.items() if k[0] == "gemm_nt_mx8" and k[1] == rows) == (4 * 11 + 1) * 2   # last block: QKV only
         assert abs(loss.item() - float(g["loss"])) <= 5e-2, (loss.item(), float(g["loss"]))
         named = dict(model.named_parameters())
         tot_h = sum(named[str(n)].grad.double().norm().item() ** 2 for n in g["grad_names"]) ** 0.5
@@ -727,3 +734,45 @@ def test_graphed_backbone_replays_bit_exact_and_faster():
     tg = timeit(lambda: gb(x))
     print(f"eager {te * 1e3:.2f} ms  graph {tg * 1e3:.2f} ms")
     assert tg < te
+
+
+@pytest.mark.parametrize("D,num_heads", [(192, None), (384, None), (192, 12)])
+def test_cls_only_last_block_vs_full_block_and_oracle(D, num_heads):
+    """ChAdaViT.cls_only_last_block (the last block on the CLS rows only when return_all_tokens = False) against the same model with
+    the flag off -- CLS features and every gradient -- and against autograd through the oracle.  The 12-head default constructor
+    (dh = 16) runs the CLS attention natively."""
+    from chadavit_amd import ops
+    from chadavit_amd.data.channels_strategies import one_channel_collate_fn
+    dev = _dev()
+    imgs = P.make_images([2, 1, 3, 10], [224], seed=72)
+    crops, labels, ncl = one_channel_collate_fn(imgs)
+    x = (crops if isinstance(crops, torch.Tensor) else crops[0]).to(dev)
+    nch = ncl[0] if isinstance(ncl[0], list) else ncl
+    wgt = P.tensor((len(nch), D), "cls.w", 1.0, seed=73).to(dev)
+    res = {}
+    for flag in (True, False):
+        m = _backbone(D, 71, dev, num_heads=num_heads)
+        m.cls_only_last_block = flag
+        with ops.LaunchProfiler() as prof:
+            out = m(x, 0, [nch])
+            (out * wgt).sum().backward()
+        n_cls = sum(v["launches"] for k, v in prof.summary().items() if k[0] in ("attn_cls_fwd", "attn_cls_bwd"))
+        assert n_cls == (2 if flag else 0)
+        res[flag] = (out.detach().float(), {n: p.grad.detach().float().clone() for n, p in m.named_parameters() if p.grad is not None})
+    (o1, g1), (o0, g0) = res[True], res[False]
+    assert _cos(o1, o0) >= 0.9999 and float((o1 - o0).abs().max()) <= 1e-2 * float(o0.abs().max()) + 1e-2   # a bf16 ulp or two
+    assert set(g1) == set(g0)
+    for n in g0:
+        if g0[n].norm() > 1e-6 * g0[n].numel() ** 0.5:
+            assert _cos(g1[n], g0[n]) >= 0.995, n
+    sd = {k: v.clone().requires_grad_(True) for k, v in P.fill_state_dict(P.backbone_shapes(D), seed=71).items()}
+    ref = R.backbone_ragged(sd, x.cpu(), nch, **({} if num_heads is None else {"nheads": num_heads, "final_eps": 1e-5}))
+    assert _cos(o1, ref.detach()) >= 0.999
+    (ref * wgt.cpu()).sum().backward()
+    tot_h = sum(v.double().norm().item() ** 2 for v in g1.values()) ** 0.5
+    tot_r = sum(sd[n].grad.double().norm().item() ** 2 for n in g1) ** 0.5
+    assert abs(tot_h - tot_r) <= 5e-2 * tot_r, (tot_h, tot_r)
+    for n in g1:
+        gr = sd[n].grad
+        if gr.norm() > 1e-6 * gr.numel() ** 0.5:
+            assert _cos(g1[n], gr) >= 0.99, n
