@@ -1,6 +1,6 @@
 #!/bin/bash
 # final measurement set of round 2 (last build): bench lines for every workload + rocprofv3 kernel stats of the default run
-TAG=r02j
+TAG=${1:-r02k}
 O=$GRAFT_REPO_ROOT/gpurun_out/final_$TAG
 mkdir -p $O
 cd $GRAFT_REPO_ROOT
