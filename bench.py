@@ -71,6 +71,8 @@ def parse():
                     "gradient norm of the N-rank data-parallel step vs the same GLOBAL batch run by one rank alone (rel <= 3e-2)")
     ap.add_argument("--overlap", action="store_true", help="force the teacher / local-crop / dW side streams on (default: on for "
                     "D >= 768 only, see ChAdaViT.dw_side_stream)")
+    ap.add_argument("--no-full-width-leg", action="store_true", help="skip the short extra measurement with the last encoder block "
+                    "at full width (reported as config.images_per_s_with_full_width_last_block)")
     ap.add_argument("--serial", action="store_true", help="one HIP stream (no teacher/local/dW side streams): per-kernel "
                     "durations in a rocprofv3 trace are then stand-alone durations (profiles/README.md)")
     return ap.parse_args()
@@ -512,6 +514,30 @@ def main():
         dt = float(t.item())
     loss_val = float(last.item())
 
+    # ---- the same step with the last encoder block at full width (what the reference executes), for the record: the default
+    # path runs that block on the CLS rows only (ChAdaViT.cls_only_last_block: identical outputs and gradients)
+    value_full = None
+    bbs = [m_ for m_ in (model.backbone, model.momentum_backbone) if getattr(m_, "cls_only_last_block", False)]
+    if bbs and not args.no_full_width_leg:
+        for m_ in bbs:
+            m_.cls_only_last_block = False
+        n_full = max(2, min(args.steps, 5))
+        for j in range(2):
+            tr.train_step(batch, args.warmup + args.steps + j)
+        barrier()
+        t1 = time.perf_counter()
+        for j in range(n_full):
+            tr.train_step(batch, args.warmup + args.steps + 2 + j)
+        barrier()
+        dtf = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([dtf], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dtf = float(t.item())
+        value_full = B * world * n_full / dtf
+        for m_ in bbs:
+            m_.cls_only_last_block = True
+
     # ---- roofline leg (rank 0): which entry points does a step launch, how often, and how long does each take?
     # One extra step is run under the launch recorder only to COUNT launches per (entry point, shape); every distinct
     # launch is then replayed back-to-back on the same stream between two HIP events (10 launches) to get its average
@@ -559,8 +585,13 @@ def main():
                        "global_batch": B * world, "parallelism": f"dp{world}", "final_loss": round(loss_val, 4),
                        "algorithmic_gflop_per_image": round(gf_img, 1), "executed_gflop_per_image": round(gf_exec, 1),
                        "achieved_tflops_per_gpu": round(step_tflops, 1),
-                       "mfma_fraction_whole_step": round(step_tflops / PEAK_BF16_TFLOPS, 4)},
+                       "mfma_fraction_whole_step": round(step_tflops / PEAK_BF16_TFLOPS, 4),
+                       "last_block": ("CLS rows only (return_all_tokens=False reads nothing else of it; same outputs and gradients as the "
+                                      "reference's full-width block; CHADAVIT_FULL_LAST_BLOCK=1 restores it)")
+                                     if model.backbone.cls_only_last_block else "full width"},
         }
+        if value_full is not None:
+            out["config"]["images_per_s_with_full_width_last_block"] = round(value_full, 2)
         # ---- roofline of the dominant instrumented kernel, from live HIP-event timings
         roof = None
         if prof_summary is not None:
