@@ -267,6 +267,11 @@ class DINO(_Base):
         self.validation_step_outputs: List[Dict[str, Any]] = []
         self.compute_ssl_val_loss = cfg.ssl_val_loss
         self.batch_crops = True  # pack same-size crops into one ragged batch per network
+        # The reference's training_step runs the student backbone on the local crops and never reads the result (no head, no loss,
+        # no gradient: SURVEY A7).  True (default) = run that pass all the same, as the reference does and as bench.py times it;
+        # False = skip it -- same loss, gradients and weights, about a tenth of the step less (out["feats"] then holds the global
+        # crops only).
+        self.compute_unused_local_pass = True
         # teacher / local-crop passes on side HIP streams (see training_step); default as for ChAdaViT.dw_side_stream: it pays
         # where the backbone runs the GEMM chain (Base), not where the fused block kernels already fill the chip
         self.overlap_streams = getattr(self.backbone, "embed_dim", 0) >= 768
@@ -440,7 +445,7 @@ class DINO(_Base):
             p = torch.cat([o["z"] for o in outs])
             feats_list = [o["feats"] for o in outs]
             momentum_p = torch.cat([self.momentum_forward(x, k)["z"] for k, x in enumerate(X[:nl])])
-        if self.multicrop:
+        if self.multicrop and self.compute_unused_local_pass:
             # local crops: student backbone only, no head, no loss, no gradient reaches them
             small = list(X[nl:])
             ctx = torch.cuda.stream(s_local) if use_streams else torch.no_grad()

@@ -776,3 +776,34 @@ def test_cls_only_last_block_vs_full_block_and_oracle(D, num_heads):
         gr = sd[n].grad
         if gr.norm() > 1e-6 * gr.numel() ** 0.5:
             assert _cos(g1[n], gr) >= 0.99, n
+
+
+def test_skipping_the_unused_local_pass_changes_nothing():
+    """DINO.compute_unused_local_pass = False: the local crops' student pass (never read by the reference's step: SURVEY A7) is skipped;
+    loss and every gradient are bit-identical to the default, which runs it."""
+    from chadavit_amd import ops
+    from chadavit_amd.data.channels_strategies import one_channel_collate_fn
+    from chadavit_amd.methods.dino import DINO
+    dev = _dev()
+    imgs = P.make_images([2, 1, 3], [224, 224, 96, 96], seed=81)
+    crops, labels, ncl = one_channel_collate_fn(imgs)
+    batch = ([c.to(dev) for c in crops], labels.to(dev), ncl)
+    res = {}
+    for flag in (True, False):
+        model = DINO(_cfg(192, 4096, 2, 2))
+        model.load_state_dict(build_sd(192, 4096))
+        model = model.to(dev)
+        model.compute_unused_local_pass = flag
+        model.current_epoch = 1
+        model.on_train_epoch_start()
+        with ops.LaunchProfiler() as prof:
+            loss = model.training_step(batch, 0)
+            loss.backward()
+        n_fwd = sum(v["launches"] for k, v in prof.summary().items() if k[0] == "attn_cls_fwd")
+        assert n_fwd == (3 if flag else 2)   # student, teacher[, local] passes
+        res[flag] = (loss.item(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+        assert len(model._last_outs["feats"]) == (4 if flag else 2)
+    assert res[True][0] == res[False][0]
+    assert set(res[True][1]) == set(res[False][1])
+    for n, g in res[True][1].items():
+        assert torch.equal(g, res[False][1][n]), n
