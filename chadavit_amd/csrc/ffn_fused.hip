@@ -142,6 +142,19 @@ struct FfnPro {
   bf16_t* QKV; int ldqkv; const float* bqkv; int qkv_at;
 };
 
+// eight bf16 values -> bit j = value j != 0 (v_pk_min_u16 by hand: hipcc expands the vector minimum into compare + select pairs)
+__device__ __forceinline__ unsigned relu_mask8(u32x4 x) {
+  const unsigned one2 = 0x00010001u;
+  unsigned m = 0u;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    unsigned f;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(f) : "v"(x[i] & 0x7FFF7FFFu), "v"(one2));  // bit 0 / bit 16 = low / high half non-zero
+    m |= f << (2 * i);
+  }
+  return (m | (m >> 15)) & 0xFFu;
+}
+
 // One pipeline step: issue the LDS-DMA of a packed block into `dst` (when `issue`), then GEMM1 of chunk k and GEMM2 of chunk
 // k-1 out of the stage `st`, bias/ReLU/convert, and (WRITE_H) the hidden-slab traffic.  Everything that touches LDS between
 // two barriers lives in THIS function, with __restrict__ pointers, on purpose: after inlining, the LDS reads carry
@@ -254,12 +267,12 @@ __device__ __forceinline__ void ffn_core(BufRsrc wrs, unsigned blk_bytes, bf16_t
         } else {
           hb[rt][r] = (bf16_t)fmaxf(hacc[rt][0][r], 0.f);
           hb[rt][4 + r] = (bf16_t)fmaxf(hacc[rt][1][r], 0.f);
-          if constexpr (MODE == 1) {  // "> 0" on the bf16 value the backward would otherwise read back from H
-            rbits |= ((float)hb[rt][r] > 0.f ? 1u : 0u) << (rt * 8 + r);
-            rbits |= ((float)hb[rt][4 + r] > 0.f ? 1u : 0u) << (rt * 8 + 4 + r);
-          }
         }
       }
+      // "> 0" on the bf16 values the backward would otherwise read back from H: they left a ReLU, so "!= 0" (sign masked off for a
+      // -0) -- a packed 16-bit minimum against 1 per dword, the four dwords merged two bits apart and folded once: 15 VALU per eight
+      // values instead of 4 per value (convert, compare, select, shift-or)
+      if constexpr (MODE == 1) rbits |= relu_mask8(__builtin_bit_cast(u32x4, hb[rt])) << (rt * 8);
       if constexpr (WRITE_H) *reinterpret_cast<bf16x8*>(sh + (w * 16 * RT + rt * 16 + li) * HROW + (k & 1) * HC + g * 8) = hb[rt];
     }
   }
