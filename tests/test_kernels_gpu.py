@@ -947,3 +947,53 @@ def test_attention_of_the_cls_rows(nch, p, D, H):
     notcls = torch.ones(T, dtype=torch.bool, device=dev)
     notcls[cls] = False
     assert float(dqkv[notcls, :D].float().abs().max()) == 0.0 if notcls.any() else True
+
+
+@pytest.mark.parametrize("D,M", [(192, 603136), (384, 278462), (768, 125504)])
+def test_row_wise_kernels_at_bench_rows_equal_their_small_runs(D, M):
+    """The HBM-bound row-wise kernels at the bench's row counts, by the same replica property as the hot kernels above: LayerNorm
+    forward / backward (+ residual), the chained LayerNorm pair backward, the QKV-backward / out-proj-backward GEMMs and the CLS gather
+    / scatter reproduce their 1024-row launches bit for bit in every copy; the column sums (dgamma / dbeta) scale with the copies."""
+    from chadavit_amd import ops
+    dev = _dev()
+    M0 = 1024
+    reps = (M + M0 - 1) // M0
+    rep = lambda t: t.repeat(reps, 1)[:M].contiguous() if t.dim() == 2 else t.repeat(reps)[:M].contiguous()
+    x0 = _rand((M0, D), 301, 2.0).bfloat16().to(dev)
+    dy0 = _rand((M0, D), 302, 1.0).bfloat16().to(dev)
+    dres0 = _rand((M0, D), 303, 1.0).bfloat16().to(dev)
+    gamma, beta = (1 + _rand((D,), 304, 0.2)).to(dev), _rand((D,), 305, 0.2).to(dev)
+    ws = ops.layernorm_bwd_workspace(D, dev)
+
+    def ln(x, dy, dres):
+        m = x.shape[0]
+        mean, rstd = torch.empty(m, device=dev), torch.empty(m, device=dev)
+        y = ops.layernorm_fwd(x, gamma, beta, 1e-5, mean=mean, rstd=rstd)
+        dg, db = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+        dx = ops.layernorm_bwd(dy, x, mean, rstd, gamma, dg, db, ws, dres=dres)
+        return y, mean, rstd, dx, dg, db
+
+    ys, ms, rs, dxs, dgs, dbs = ln(x0, dy0, dres0)
+    yb, mb, rb_, dxb, dgb, dbb = ln(rep(x0), rep(dy0), rep(dres0))
+    assert torch.equal(yb, rep(ys)) and torch.equal(mb, rep(ms)) and torch.equal(rb_, rep(rs)) and torch.equal(dxb, rep(dxs))
+    full, tail = M // M0, M % M0
+    if tail == 0:
+        assert float((dgb - full * dgs).norm() / (full * dgs).norm()) < 1e-4 and float((dbb - full * dbs).norm() / (full * dbs).norm()) < 1e-4
+    del yb, dxb
+    # GEMMs of the backward: dh = dqkv Wqkv ([M, 3D] x [3D, D]) and da = dy Wo ([M, D] x [D, D])
+    wq = (_rand((D, 3 * D), 306, 1.0) / math.sqrt(3 * D)).bfloat16().to(dev)   # = in_proj_weight^T, [N = D, K = 3D]
+    wo = (_rand((D, D), 307, 1.0) / math.sqrt(D)).bfloat16().to(dev)
+    dqkv0 = _rand((M0, 3 * D), 308, 1.0).bfloat16().to(dev)
+    assert torch.equal(ops.gemm_nt(rep(dqkv0), wq), rep(ops.gemm_nt(dqkv0, wq)))
+    assert torch.equal(ops.gemm_nt(rep(dy0), wo), rep(ops.gemm_nt(dy0, wo)))
+    assert torch.equal(ops.gemm_nt(rep(dy0), wo, epilogue=ops.EPI_RESID, aux=rep(dres0)), rep(ops.gemm_nt(dy0, wo, epilogue=ops.EPI_RESID, aux=dres0)))
+    # CLS gather / scatter over the bench's sequence count
+    n_seq = M // 1961 if D > 192 else M // 589
+    rows = (torch.arange(n_seq, device=dev, dtype=torch.int32) * (M // n_seq)).contiguous()
+    big = rep(x0)
+    g = ops.gather_rows(big, rows)
+    assert torch.equal(g, big[rows.long()])
+    sc = ops.scatter_rows_zero(g, rows, M)
+    ref = torch.zeros_like(big)
+    ref[rows.long()] = g
+    assert torch.equal(sc, ref)
