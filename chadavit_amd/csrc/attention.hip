@@ -377,8 +377,6 @@ __global__ __launch_bounds__(64 * FwdDmaCfg<DH>::NW, (DH <= 192 ? 2 : 1)) void a
   if (qt * TILE + part * QPB >= len) return;
   const size_t ld = 3 * (size_t)D;
   const bf16_t* qbase = qkv + (size_t)seq0 * ld + h * DH;
-  const bf16_t* kbase = qbase + D;
-  const bf16_t* vbase = qbase + 2 * D;
   const float c = scale * LOG2E;
 
   bf16x8 qf[CB][KS];

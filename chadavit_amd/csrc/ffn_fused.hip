@@ -314,7 +314,7 @@ __global__ __launch_bounds__(64 * NWV, (RT * NWV <= 8 ? 2 : 1)) void ffn_fwd_ker
   // WRITE_H: per-wave slab where two consecutive hidden chunks (64 units = 128 B per row) are gathered before they are
   // written out as full 128-byte row segments (8 rows per store instruction); row stride 144 B keeps the b128 writes
   // conflict-free
-  constexpr int HROW = 72;                       // bf16 elements per staged row (64 + 8 pad)
+  // (72 bf16 elements per staged row = 64 + 8 pad: HROW in ffn_core, SH_ELEMS above)
   constexpr int NPEND = WRITE_H ? RT * 2 : 1;    // 16-byte pieces per lane per chunk pair
   bf16_t* const sH = smem + NST * STAGE + 2 * MAX_FF;
   const int tid = threadIdx.x, l = tid & 63, li = l & 15, g = l >> 4;
