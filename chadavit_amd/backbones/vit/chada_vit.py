@@ -23,7 +23,7 @@ import torch.nn.functional as F
 
 from ... import ops
 from ...flat import FlatParams
-from ...ragged import RaggedBatch
+from ...ragged import RaggedBatch, ragged_batch
 
 FFN_DIM = 2048  # hard-wired in the reference (chada_vit.py:160)
 # one fused-FFN block owns 128 token rows for the whole hidden range: below ~1 block per CU the two-GEMM path (which also
@@ -208,7 +208,7 @@ class ChAdaViT(nn.Module):
         if S % ps != 0:
             raise RuntimeError("crop side must be a multiple of the patch size")
         if rb is None:
-            rb = RaggedBatch(num_channels, (S // ps) ** 2, x.device)
+            rb = ragged_batch(num_channels, (S // ps) ** 2, x.device)
         flat = self.flat_params()
         pos_patch = self.patch_pos_embed(S, S)
         add_chan = (max_channels == self.max_channels)

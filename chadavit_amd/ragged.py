@@ -60,3 +60,21 @@ class RaggedBatch:
     @property
     def host_cu_seqlens(self) -> List[int]:
         return self._host_cu
+
+
+# The student and the teacher pass of one step (and every step of a fixed-channel dataset) describe the same batch: the index
+# arrays are built and uploaded once.  Read-only on the device; a handful of entries of a few hundred KiB.
+_CACHE: "dict" = {}
+_CACHE_MAX = 8
+
+
+def ragged_batch(num_channels: Sequence[int], patches_per_channel: int, device) -> RaggedBatch:
+    key = (tuple(int(c) for c in num_channels), int(patches_per_channel), str(device))
+    rb = _CACHE.pop(key, None)
+    if rb is None:
+        rb = RaggedBatch(key[0], patches_per_channel, device)
+        while len(_CACHE) >= _CACHE_MAX:
+            _CACHE.pop(next(iter(_CACHE)))
+    _CACHE[key] = rb   # most recently used last
+    return rb
+

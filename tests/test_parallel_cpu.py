@@ -248,3 +248,15 @@ def test_bench_mixed_channel_batches_are_token_balanced_across_ranks():
             assert max(tokens) / min(tokens) - 1.0 <= 0.02, (world, B, tokens)
         naive = [sum(1 + c * 196 for c in bench.channel_list("1-10", 32, seed=1000 + r)) for r in range(world)]
         assert max(naive) / min(naive) - 1.0 > 0.02  # what the sampler is there to avoid
+
+
+def test_ragged_batch_cache_returns_the_same_description():
+    from chadavit_amd.ragged import _CACHE, _CACHE_MAX, ragged_batch
+    dev = torch.device("cpu")
+    a = ragged_batch([3, 1, 2], 196, dev)
+    assert ragged_batch((3, 1, 2), 196, dev) is a and ragged_batch([3, 1, 2], 36, dev) is not a
+    for i in range(2 * _CACHE_MAX):
+        ragged_batch([i + 1], 4, dev)
+    assert len(_CACHE) == _CACHE_MAX
+    b = ragged_batch([3, 1, 2], 196, dev)   # evicted meanwhile: rebuilt, same content
+    assert b is not a and torch.equal(b.cu_seqlens, a.cu_seqlens) and torch.equal(b.work, a.work) and b.T == a.T
