@@ -67,8 +67,12 @@ def parse():
     ap.add_argument("--batch", type=int, default=0, help="images per GPU (0 = workload default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-launch-profile", action="store_true")
-    ap.add_argument("--verify-equal-batch", action="store_true", help="N > 1 self-check before the timed region: loss and "
-                    "gradient norm of the N-rank data-parallel step vs the same GLOBAL batch run by one rank alone (rel <= 3e-2)")
+    ap.add_argument("--verify-equal-batch", action="store_true", help="(default when N > 1; kept for older command lines) self-check "
+                    "before the timed region: loss and gradient norm of the N-rank data-parallel step vs the same GLOBAL batch run by "
+                    "one rank alone (rel <= 3e-2)")
+    ap.add_argument("--no-verify-equal-batch", action="store_true", help="skip that self-check (two small extra steps per rank)")
+    ap.add_argument("--no-other-workloads", action="store_true", help="N = 1 only: skip the short cfg3 / cfg5 legs run after the "
+                    "headline measurement (reported as config.other_workloads)")
     ap.add_argument("--overlap", action="store_true", help="force the teacher / local-crop / dW side streams on (default: on for "
                     "D >= 768 only, see ChAdaViT.dw_side_stream)")
     ap.add_argument("--no-full-width-leg", action="store_true", help="skip the short extra measurement with the last encoder block "
@@ -236,6 +240,7 @@ def verify_equal_batch(model, gs, wl, rank, world, dev, per_rank=4):
     hooks = (model.backbone.grad_ready_hook, model.head.grad_ready_hook)
 
     def run(batch, synced):
+        model.dino_loss_func.sync_center()
         model.dino_loss_func.center.copy_(center0)
         model.backbone.grad_ready_hook, model.head.grad_ready_hook = hooks if synced else (None, None)
         for p in model.parameters():
@@ -259,6 +264,7 @@ def verify_equal_batch(model, gs, wl, rank, world, dev, per_rank=4):
     dist.all_reduce(t)
     loss_b = float(t.item()) / world
     model.backbone.grad_ready_hook, model.head.grad_ready_hook = hooks
+    model.dino_loss_func.sync_center()
     model.dino_loss_func.center.copy_(center0)
     for p in model.parameters():
         p.grad = None
@@ -429,29 +435,12 @@ def replay_launches(counts, nch, wl, dev, reps=10):
     return out
 
 
-def main():
-    args = parse()
-    world_env = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and world_env == 1:
-        # plain `python bench.py --gpus N`: start the ranks as child processes (never exec after touching the GPU)
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29541"), os.path.abspath(__file__)] + sys.argv[1:]
-        sys.exit(subprocess.call(cmd))
-
+def build_workload(wl, args, rank, world, dev):
+    """Model + Trainer (+ GradSync) + one synthetic batch resident in HBM for a WORKLOADS entry."""
     import torch
-    import torch.distributed as dist
-    from chadavit_amd import ops
     from chadavit_amd.methods.dino import DINO
-    from chadavit_amd.parallel import GradSync, init_from_env
+    from chadavit_amd.parallel import GradSync
     from chadavit_amd.trainer import Trainer
-
-    rank, world, local = init_from_env()
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: chadavit_amd has no CPU path")
-    dev = torch.device("cuda", local)
-    wl = dict(WORKLOADS[args.workload])
-    if args.batch:
-        wl["batch"] = args.batch
     B = wl["batch"]
     torch.manual_seed(0)
     model = DINO(make_cfg(wl)).to(dev)
@@ -490,6 +479,192 @@ def main():
     steps_per_epoch = 1000
     gs = GradSync() if world > 1 else None
     tr = Trainer(max_epochs=100, steps_per_epoch=steps_per_epoch, grad_sync=gs).attach(model)
+    return model, tr, gs, batch, nch, tokens_per_rank
+
+
+def roofline_object(prof_summary, model, nch, wl):
+    """(roofline dict, top entry points) of one workload from its launch profile ({key: {launches, avg_us, total_ms[, in_step_avg_us]}})."""
+    top_list = None
+    # ---- roofline of the dominant instrumented kernel, from live HIP-event timings
+    roof = None
+    if prof_summary is not None:
+        summ = prof_summary
+        tot_ms = sum(v["total_ms"] for v in summ.values())
+        key = max(summ, key=lambda k: summ[k]["total_ms"])
+        st = dict(summ[key])
+        # the dominant kernel's duration for the roofline: its launches timed INSIDE ordinary training steps (HIP events on the
+        # launch stream) -- that is what rocprofv3 --kernel-trace of this command reports for it too (profiles/: within 2 %).
+        # The back-to-back replay of one kernel on fresh random operands runs hotter (the part's power budget, DESIGN.md 5d)
+        # and reads up to 10 % longer; it stays in the line as avg_us_replay.  With side streams on, the in-step figure
+        # includes CU sharing with the kernels beside it, and the replay remains the reference.
+        st["replay_avg_us"] = st["avg_us"]
+        if "in_step_avg_us" in st and not model.backbone.dw_side_stream:
+            st["avg_us"] = st["in_step_avg_us"]
+        sumsq = {}
+        p224, p96 = 196, 36
+        tg = sum(1 + c * p224 for c in nch) * wl["n_global"]
+        sumsq[tg] = sum((1 + c * p224) ** 2 for c in nch) * wl["n_global"]
+        if wl["n_local"]:
+            tl = sum(1 + c * p96 for c in nch) * wl["n_local"]
+            sumsq[tl] = sum((1 + c * p96) ** 2 for c in nch) * wl["n_local"]
+        name = key[0]
+        peak_tf = PEAK_BF16_TFLOPS
+        if name == "gemm_nt":
+            flops, bound = 2.0 * key[1] * key[2] * key[3], "mfma"
+        elif name == "gemm_nt_mx8":
+            flops, bound, peak_tf = 2.0 * key[1] * key[2] * key[3], "mfma", PEAK_MXFP8_TFLOPS
+        elif name == "gemm_tn":
+            flops, bound = 2.0 * key[1] * key[2] * key[3], "mfma"
+        elif name in ("ffn_fwd", "ffn_ln_fwd"):
+            flops, bound = 4.0 * key[1] * key[2] * key[3], "mfma"
+        elif name == "ffn_bwd_dx":  # dH = dz W2 and dx1 += dH W1
+            flops, bound = 4.0 * key[1] * key[2] * key[3], "mfma"
+        elif name == "proj_ffn_ln_fwd":  # + the D x D projection (+ the next block's D x 3D QKV projection)
+            flops, bound = 4.0 * key[1] * key[2] * key[3] + 2.0 * key[1] * key[2] * key[2] * (4 if key[6] else 1), "mfma"
+        elif name == "attn_fwd":
+            flops, bound = 4.0 * sumsq.get(key[1], 0) * key[2], "mfma"
+        elif name == "attn_bwd":
+            flops, bound = 10.0 * sumsq.get(key[1], 0) * key[2], "mfma"
+        else:
+            flops, bound = None, "hbm"
+        if bound == "mfma":
+            ach = flops / (st["avg_us"] * 1e-6) / 1e12
+            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak_tf, "unit": "TFLOP/s",
+                    "frac": round(ach / peak_tf, 4), "traffic": None}
+            if peak_tf == PEAK_BF16_TFLOPS:
+                # BASELINE.md: restate the peak at the clock observed on the box.  Back-to-back bf16 MFMAs on every SIMD sustain
+                # 1.64-1.85 PFLOP/s on random operands (the shader clock falls to 1.65-1.84 GHz; 2.3-2.4 PFLOP/s at 2.3-2.4 GHz
+                # on all-zero operands): scratch/sstore/mfma_rate.hip, DESIGN.md 5c
+                roof["peak_sustained_random_operands"] = SUSTAINED_BF16_TFLOPS
+                roof["frac_of_sustained"] = round(ach / SUSTAINED_BF16_TFLOPS, 4)
+            if name == "gemm_nt":  # at D=192 a stand-alone GEMM is below machine balance: HBM is the roof that binds
+                M_, N_, K_, epi_ = key[1], key[2], key[3], key[4]
+                nbytes = 2.0 * (M_ * K_ + N_ * K_ + M_ * N_ * (2 if epi_ in (3, 4, 5) else 1))
+                gbs = nbytes / (st["avg_us"] * 1e-6) / 1e9
+                if flops / nbytes < PEAK_BF16_TFLOPS * 1e3 / PEAK_HBM_GBS:
+                    roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                            "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None, "mfma_tflops": round(ach, 2),
+                            "mfma_frac": round(ach / PEAK_BF16_TFLOPS, 4)}
+                else:
+                    roof["hbm_gbs"] = round(gbs, 1)
+                    roof["hbm_frac"] = round(gbs / PEAK_HBM_GBS, 4)
+                roof["algorithmic_bytes"] = nbytes
+                roof["flop_per_byte"] = round(flops / nbytes, 1)
+        else:
+            nbytes = key[1] * key[2] * 2 * (2 if name == "layernorm_fwd" else 4)
+            ach = nbytes / (st["avg_us"] * 1e-6) / 1e9
+            roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None}
+        # HBM bytes of this kernel from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, collected separately and
+        # committed under profiles/ -- see profiles/pmc_traffic.json for the correction applied)
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                pmc = json.load(f).get("/".join(str(k) for k in key))
+            if pmc:
+                roof["traffic"] = pmc["traffic_bytes"]
+                if roof["bound"] == "mfma":  # the same launch against the OTHER roof: measured HBM bytes over its duration
+                    gbs = pmc["traffic_bytes"] / (st["avg_us"] * 1e-6) / 1e9
+                    roof["hbm_gbs"] = round(gbs, 1)
+                    roof["hbm_frac"] = round(gbs / PEAK_HBM_GBS, 4)
+        except OSError:
+            pass
+        roof.update({"kernel": "/".join(str(k) for k in key), "avg_us": round(st["avg_us"], 2),
+                     "avg_us_in_step": round(st.get("in_step_avg_us", float("nan")), 2), "avg_us_replay": round(st["replay_avg_us"], 2),
+                     "streams": "overlapped" if model.backbone.dw_side_stream else "serial",
+                     "launches_per_step": st["launches"],
+                     "share_of_instrumented_gpu_time": round(st["total_ms"] / tot_ms, 4),
+                     "instrumented_ms_per_step": round(tot_ms, 3)})
+        if "in_step_avg_us" in st:  # same figure priced with the live (possibly CU-sharing) duration
+            roof["frac_in_step"] = round(roof["frac"] * st["avg_us"] / st["in_step_avg_us"], 4)
+        top = sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"])[:int(os.environ.get("BENCH_TOP", "12"))]
+        top_list = [{"kernel": "/".join(str(x) for x in k), "ms_per_step": round(v["total_ms"], 3),
+                                      "avg_us": round(v["avg_us"], 1), "launches_per_step": v["launches"]} for k, v in top]
+    return roof, top_list
+
+
+def launch_profile(tr, batch, step0, nch, wl, dev, rank, in_step_steps=2):
+    """Which entry points does a step launch, how often, and how long does each take?  One extra step runs under the launch
+    recorder only to COUNT launches per (entry point, shape); every distinct launch is then replayed back-to-back on the same
+    stream between two HIP events (10 launches); the dominant one is timed again INSIDE `in_step_steps` further ordinary steps
+    with HIP events around only its launches (on the stream each is launched on).  Every rank runs the same extra steps (they
+    contain the gradient collectives); only rank 0 records and replays."""
+    import contextlib
+    from chadavit_amd import ops
+    with (ops.LaunchProfiler() if rank == 0 else contextlib.nullcontext()) as prof:
+        tr.train_step(batch, step0)
+    dom = None
+    summ = None
+    if rank == 0:
+        counts = {k: v["launches"] for k, v in prof.summary().items()}
+        summ = replay_launches(counts, nch, wl, dev)
+        dom = max(summ, key=lambda k: summ[k]["total_ms"])
+    with (ops.LaunchProfiler(only=dom) if rank == 0 else contextlib.nullcontext()) as live:
+        for j in range(in_step_steps):
+            tr.train_step(batch, step0 + 1 + j)
+    if rank == 0:
+        summ[dom]["in_step_avg_us"] = live.summary()[dom]["avg_us"]
+    return summ
+
+
+def other_workload_leg(name, args, dev, steps=3, warmup=2):
+    """A short leg of another BASELINE.json config on the same box, after the headline measurement (N = 1): images/s over
+    `steps` steps, the dominant entry point and its roofline fraction -- so that the driver's own bench record carries numbers
+    for configs[2] / configs[4] too.  Same step, same code path as a `--workload NAME` run."""
+    import gc
+    import torch
+    wl = dict(WORKLOADS[name])
+    model, tr, _, batch, nch, _ = build_workload(wl, args, 0, 1, dev)
+    for i in range(warmup):
+        tr.train_step(batch, i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        last = tr.train_step(batch, warmup + i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    res = {"workload": wl["desc"], "images_per_gpu": wl["batch"], "images_per_s": round(wl["batch"] * steps / dt, 2),
+           "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps, "warmup": warmup, "final_loss": round(float(last.item()), 4),
+           "dtype": "fp8-weights (MX e4m3 x e4m3 forward GEMMs; bf16 elsewhere)" if wl.get("weight_dtype") == "fp8" else "bf16"}
+    chans = list(range(1, 11)) if "-" in wl["channels"] else [int(wl["channels"])]
+    gf_exec = gflop_per_image(chans, wl["D"], wl["P"], wl["n_global"], wl["n_local"], cls_last=bool(model.backbone.cls_only_last_block))
+    res["executed_gflop_per_image"] = round(gf_exec, 1)
+    res["mfma_fraction_whole_step"] = round(res["images_per_s"] * gf_exec / 1e3 / PEAK_BF16_TFLOPS, 4)
+    if not args.no_launch_profile:
+        summ = launch_profile(tr, batch, warmup + steps, nch, wl, dev, 0, in_step_steps=1)
+        roof, _ = roofline_object(summ, model, nch, wl)
+        res.update({"dominant_kernel": roof["kernel"], "dominant_avg_us": roof["avg_us"], "bound": roof["bound"], "frac": roof["frac"],
+                    "achieved": roof["achieved"], "unit": roof["unit"], "share_of_instrumented_gpu_time": roof["share_of_instrumented_gpu_time"]})
+    del model, tr, batch
+    gc.collect()
+    torch.cuda.empty_cache()
+    return res
+
+
+def main():
+    args = parse()
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world_env == 1:
+        # plain `python bench.py --gpus N`: start the ranks as child processes (never exec after touching the GPU)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29541"), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
+    import torch
+    import torch.distributed as dist
+    from chadavit_amd import ops
+    from chadavit_amd.methods.dino import DINO
+    from chadavit_amd.parallel import GradSync, init_from_env
+    from chadavit_amd.trainer import Trainer
+
+    rank, world, local = init_from_env()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: chadavit_amd has no CPU path")
+    dev = torch.device("cuda", local)
+    wl = dict(WORKLOADS[args.workload])
+    if args.batch:
+        wl["batch"] = args.batch
+    B = wl["batch"]
+    model, tr, gs, batch, nch, tokens_per_rank = build_workload(wl, args, rank, world, dev)
 
     def barrier():
         if world > 1:
@@ -497,22 +672,38 @@ def main():
         torch.cuda.synchronize()
 
     verify = None
-    if args.verify_equal_batch and world > 1:
+    if world > 1 and not args.no_verify_equal_batch:  # on by default: the first N-GPU run has no other witness
         verify = verify_equal_batch(model, gs, wl, rank, world, dev)
     for i in range(args.warmup):
         tr.train_step(batch, i)
+    if gs is not None:
+        gs.reducer.timing = True   # HIP events around the compute <- communication hand-over of every timed step
     barrier()
     t0 = time.perf_counter()
     last = None
     for i in range(args.steps):
         last = tr.train_step(batch, args.warmup + i)
+    torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0   # this rank's own time to finish its K steps (before waiting for the others)
     barrier()
     dt = time.perf_counter() - t0
+    comm_timing = None
+    rank_ms = None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        gs.reducer.timing = False
+        mine = gs.reducer.timing_summary() or {}
+        per = torch.tensor([1e3 * dt_local / args.steps, mine.get("exposed_ms_per_step") or 0.0, mine.get("comm_busy_ms_per_step") or 0.0],
+                           device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(per) for _ in range(world)]
+        dist.all_gather(allr, per)
+        rank_ms = [round(float(a[0]), 3) for a in allr]
+        comm_timing = {"exposed_ms_per_step_per_rank": [round(float(a[1]), 4) for a in allr],
+                       "comm_busy_ms_per_step_per_rank": [round(float(a[2]), 4) for a in allr]}
     loss_val = float(last.item())
+    loss_mean = model.logged_metrics().get("dino_loss_train") if hasattr(model, "logged_metrics") else None  # sync_dist mean (collective)
 
     # ---- the same step with the last encoder block at full width (what the reference executes), for the record: the default
     # path runs that block on the CLS rows only (ChAdaViT.cls_only_last_block: identical outputs and gradients)
@@ -538,29 +729,11 @@ def main():
         for m_ in bbs:
             m_.cls_only_last_block = True
 
-    # ---- roofline leg (rank 0): which entry points does a step launch, how often, and how long does each take?
-    # One extra step is run under the launch recorder only to COUNT launches per (entry point, shape); every distinct
-    # launch is then replayed back-to-back on the same stream between two HIP events (10 launches) to get its average
-    # duration without host/recorder interference.  rocprofv3 --kernel-trace of this same command agrees (profiles/).
+    # ---- roofline leg: launch counts of one recorded step, each distinct launch replayed between HIP events, the dominant one
+    # timed again inside ordinary steps (launch_profile).  rocprofv3 --kernel-trace of this same command agrees (profiles/).
     prof_summary = None
     if not args.no_launch_profile:
-        # every rank runs the same extra steps (they contain the gradient collectives); only rank 0 records and replays
-        import contextlib
-        with (ops.LaunchProfiler() if rank == 0 else contextlib.nullcontext()) as prof:
-            tr.train_step(batch, args.warmup + args.steps)
-        dom = None
-        if rank == 0:
-            counts = {k: v["launches"] for k, v in prof.summary().items()}
-            prof_summary = replay_launches(counts, nch, wl, dev)
-            dom = max(prof_summary, key=lambda k: prof_summary[k]["total_ms"])
-        # the dominant key again, this time live: HIP events around only ITS launches (on the stream each is launched on)
-        # inside two further ordinary training steps -- with the side streams on, this includes CU sharing with the
-        # kernels running beside it
-        with (ops.LaunchProfiler(only=dom) if rank == 0 else contextlib.nullcontext()) as live:
-            for j in range(2):
-                tr.train_step(batch, args.warmup + args.steps + 1 + j)
-        if rank == 0:
-            prof_summary[dom]["in_step_avg_us"] = live.summary()[dom]["avg_us"]
+        prof_summary = launch_profile(tr, batch, args.warmup + args.steps, nch, wl, dev, rank)
     if world > 1:
         dist.barrier()
 
@@ -592,100 +765,9 @@ def main():
         }
         if value_full is not None:
             out["config"]["images_per_s_with_full_width_last_block"] = round(value_full, 2)
-        # ---- roofline of the dominant instrumented kernel, from live HIP-event timings
         roof = None
         if prof_summary is not None:
-            summ = prof_summary
-            tot_ms = sum(v["total_ms"] for v in summ.values())
-            key = max(summ, key=lambda k: summ[k]["total_ms"])
-            st = dict(summ[key])
-            # the dominant kernel's duration for the roofline: its launches timed INSIDE ordinary training steps (HIP events on the
-            # launch stream) -- that is what rocprofv3 --kernel-trace of this command reports for it too (profiles/: within 2 %).
-            # The back-to-back replay of one kernel on fresh random operands runs hotter (the part's power budget)
-            # and reads up to 10 % longer; it stays in the line as avg_us_replay.  With side streams on, the in-step figure
-            # includes CU sharing with the kernels beside it, and the replay remains the reference.
-            st["replay_avg_us"] = st["avg_us"]
-            if "in_step_avg_us" in st and not model.backbone.dw_side_stream:
-                st["avg_us"] = st["in_step_avg_us"]
-            sumsq = {}
-            p224, p96 = 196, 36
-            tg = sum(1 + c * p224 for c in nch) * wl["n_global"]
-            sumsq[tg] = sum((1 + c * p224) ** 2 for c in nch) * wl["n_global"]
-            if wl["n_local"]:
-                tl = sum(1 + c * p96 for c in nch) * wl["n_local"]
-                sumsq[tl] = sum((1 + c * p96) ** 2 for c in nch) * wl["n_local"]
-            name = key[0]
-            peak_tf = PEAK_BF16_TFLOPS
-            if name == "gemm_nt":
-                flops, bound = 2.0 * key[1] * key[2] * key[3], "mfma"
-            elif name == "gemm_nt_mx8":
-                flops, bound, peak_tf = 2.0 * key[1] * key[2] * key[3], "mfma", PEAK_MXFP8_TFLOPS
-            elif name == "gemm_tn":
-                flops, bound = 2.0 * key[1] * key[2] * key[3], "mfma"
-            elif name in ("ffn_fwd", "ffn_ln_fwd"):
-                flops, bound = 4.0 * key[1] * key[2] * key[3], "mfma"
-            elif name == "ffn_bwd_dx":  # dH = dz W2 and dx1 += dH W1
-                flops, bound = 4.0 * key[1] * key[2] * key[3], "mfma"
-            elif name == "proj_ffn_ln_fwd":  # + the D x D projection (+ the next block's D x 3D QKV projection)
-                flops, bound = 4.0 * key[1] * key[2] * key[3] + 2.0 * key[1] * key[2] * key[2] * (4 if key[6] else 1), "mfma"
-            elif name == "attn_fwd":
-                flops, bound = 4.0 * sumsq.get(key[1], 0) * key[2], "mfma"
-            elif name == "attn_bwd":
-                flops, bound = 10.0 * sumsq.get(key[1], 0) * key[2], "mfma"
-            else:
-                flops, bound = None, "hbm"
-            if bound == "mfma":
-                ach = flops / (st["avg_us"] * 1e-6) / 1e12
-                roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak_tf, "unit": "TFLOP/s",
-                        "frac": round(ach / peak_tf, 4), "traffic": None}
-                if peak_tf == PEAK_BF16_TFLOPS:
-                    # restate the peak at the clock observed on the box.  Back-to-back bf16 MFMAs on every SIMD sustain
-                    # 1.64-1.85 PFLOP/s on random operands (the shader clock falls to 1.65-1.84 GHz; 2.3-2.4 PFLOP/s at 2.3-2.4 GHz
-                    # on all-zero operands): scratch/sstore/mfma_rate.hip, DESIGN.md 5c
-                    roof["peak_sustained_random_operands"] = SUSTAINED_BF16_TFLOPS
-                    roof["frac_of_sustained"] = round(ach / SUSTAINED_BF16_TFLOPS, 4)
-                if name == "gemm_nt":  # at D=192 a stand-alone GEMM is below machine balance: HBM is the roof that binds
-                    M_, N_, K_, epi_ = key[1], key[2], key[3], key[4]
-                    nbytes = 2.0 * (M_ * K_ + N_ * K_ + M_ * N_ * (2 if epi_ in (3, 4, 5) else 1))
-                    gbs = nbytes / (st["avg_us"] * 1e-6) / 1e9
-                    if flops / nbytes < PEAK_BF16_TFLOPS * 1e3 / PEAK_HBM_GBS:
-                        roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None, "mfma_tflops": round(ach, 2),
-                                "mfma_frac": round(ach / PEAK_BF16_TFLOPS, 4)}
-                    else:
-                        roof["hbm_gbs"] = round(gbs, 1)
-                        roof["hbm_frac"] = round(gbs / PEAK_HBM_GBS, 4)
-                    roof["algorithmic_bytes"] = nbytes
-                    roof["flop_per_byte"] = round(flops / nbytes, 1)
-            else:
-                nbytes = key[1] * key[2] * 2 * (2 if name == "layernorm_fwd" else 4)
-                ach = nbytes / (st["avg_us"] * 1e-6) / 1e9
-                roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None}
-            # HBM bytes of this kernel from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, collected separately and
-            # committed under profiles/ -- see profiles/pmc_traffic.json for the correction applied)
-            try:
-                with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                    pmc = json.load(f).get("/".join(str(k) for k in key))
-                if pmc:
-                    roof["traffic"] = pmc["traffic_bytes"]
-                    if roof["bound"] == "mfma":  # the same launch against the OTHER roof: measured HBM bytes over its duration
-                        gbs = pmc["traffic_bytes"] / (st["avg_us"] * 1e-6) / 1e9
-                        roof["hbm_gbs"] = round(gbs, 1)
-                        roof["hbm_frac"] = round(gbs / PEAK_HBM_GBS, 4)
-            except OSError:
-                pass
-            roof.update({"kernel": "/".join(str(k) for k in key), "avg_us": round(st["avg_us"], 2),
-                         "avg_us_in_step": round(st.get("in_step_avg_us", float("nan")), 2), "avg_us_replay": round(st["replay_avg_us"], 2),
-                         "streams": "overlapped" if model.backbone.dw_side_stream else "serial",
-                         "launches_per_step": st["launches"],
-                         "share_of_instrumented_gpu_time": round(st["total_ms"] / tot_ms, 4),
-                         "instrumented_ms_per_step": round(tot_ms, 3)})
-            if "in_step_avg_us" in st:  # same figure priced with the live (possibly CU-sharing) duration
-                roof["frac_in_step"] = round(roof["frac"] * st["avg_us"] / st["in_step_avg_us"], 4)
-            top = sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"])[:int(os.environ.get("BENCH_TOP", "12"))]
-            out["launch_profile_top"] = [{"kernel": "/".join(str(x) for x in k), "ms_per_step": round(v["total_ms"], 3),
-                                          "avg_us": round(v["avg_us"], 1), "launches_per_step": v["launches"]} for k, v in top]
+            roof, out["launch_profile_top"] = roofline_object(prof_summary, model, nch, wl)
         out["roofline"] = roof
         if tokens_per_rank is not None:
             out["config"]["tokens_per_rank"] = tokens_per_rank
@@ -697,9 +779,33 @@ def main():
                        "spans": len(red.spans) if red is not None else 0,
                        "bytes_per_step": (red.bytes if red is not None else 0) + (4 * wl["P"] if world > 1 else 0),
                        "grad_op": "all_reduce(AVG) per block span on a side stream, overlapped with backward" if world > 1 else None,
-                       "center_op": "all_reduce(SUM) of the teacher-logit column sum" if world > 1 else None}
+                       "center_op": ("all_reduce(SUM) of the teacher-logit column sum, started on the communication stream after the loss "
+                                     "and consumed by the next step's centre EMA") if world > 1 else None}
+        if comm_timing is not None:
+            # exposed = how long the compute stream waited for the last gradient collective after its own backward work was done
+            # (communication NOT hidden behind the backward); busy = first collective issued -> last one complete
+            ex = comm_timing["exposed_ms_per_step_per_rank"]
+            out["rccl"].update({"exposed_ms_per_step": max(ex), "exposed_fraction_of_step": round(max(ex) / ms, 4), **comm_timing})
+            out["step_ms_per_rank"] = rank_ms   # each rank's own K-step time / K (the value above uses the slowest rank + barrier)
+            out["step_ms_rank_spread"] = round(max(rank_ms) / min(rank_ms) - 1.0, 4)
+            out["config"]["logged_loss_mean_over_ranks"] = None if loss_mean is None else round(float(loss_mean), 4)
         if verify is not None:
             out["verify_equal_batch"] = verify
+        if world == 1 and not args.no_other_workloads and args.workload == "cfg2":
+            # driver-visible numbers for BASELINE.json configs[2] / configs[4] (their single-GPU share): short legs AFTER the headline
+            # measurement, models built and released one at a time
+            import gc
+            del tr, batch
+            model = None
+            gc.collect()
+            torch.cuda.empty_cache()
+            legs = {}
+            for name in ("cfg3", "cfg5"):
+                try:
+                    legs[name] = other_workload_leg(name, args, dev)
+                except Exception as e:  # noqa: BLE001 - the headline number must still be reported
+                    legs[name] = {"error": repr(e)}
+            out["config"]["other_workloads"] = legs
         if world == 1 and not args.no_cpu_baseline:
             threads = min(os.cpu_count() or 1, 128)
             try:

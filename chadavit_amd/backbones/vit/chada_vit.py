@@ -209,6 +209,8 @@ class ChAdaViT(nn.Module):
             raise RuntimeError("crop side must be a multiple of the patch size")
         if rb is None:
             rb = ragged_batch(num_channels, (S // ps) ** 2, x.device)
+        else:
+            rb.use_on_current_stream()
         flat = self.flat_params()
         pos_patch = self.patch_pos_embed(S, S)
         add_chan = (max_channels == self.max_channels)
@@ -564,6 +566,9 @@ class _BackboneFn(torch.autograd.Function):
         ctx.m, ctx.rb, ctx.add_chan, ctx.need_grad = m, rb, add_chan, need_grad
         ctx.saved_blocks = saved_blocks if need_grad else None
         ctx.patches = patches if need_grad else None
+        # `patches` may be a VIEW of the caller's crop buffer (fp32 contiguous input): it must stay untouched until backward, and
+        # as a plain ctx attribute it is outside autograd's own version check -- so keep the counter and check it there
+        ctx.patches_version = patches._version if need_grad else None
         ctx.pos_needs_grad = pos_patch.requires_grad
         ctx.pos_direct = pos_direct
         ctx.n_params = len(params)
@@ -634,6 +639,9 @@ class _BackboneFn(torch.autograd.Function):
         dpatch, dpos, dchan, dcls = ops.tokenizer_bwd(dx, rb.cu_seqlens, rb.chan_img, rb.chan_idx, rb.p, m.max_channels)
         gw = G("token_learner.proj.weight")
         # the unfolded patches exist only here, for the weight gradient of the patch conv (the forward gathers them on the fly)
+        if ctx.patches._version != ctx.patches_version:
+            raise RuntimeError("the crop buffer handed to ChAdaViT.forward was modified in place between forward and backward: the "
+                               "patch-conv weight gradient reads it (keep crop buffers immutable until backward, or pass a copy)")
         patches = ops.im2col(ctx.patches, m.token_learner.patch_size)
         ops.gemm_tn(dpatch, patches, gw.view(D, -1), colsum=G("token_learner.proj.bias"), accumulate=acc, workspace=tn_ws,
                     t_rows=rb.n_chan * rb.p)

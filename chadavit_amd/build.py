@@ -12,7 +12,12 @@ CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libchadavit_hip.so")
 SOURCES = ["gemm_nt.hip", "ffn_fused.hip", "ffn_fused_d384.hip", "gemm_tn.hip", "layernorm.hip", "attention.hip", "attention_cls.hip", "tokenizer.hip", "dino_ops.hip", "gemm_mx8.hip", "augment.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# -packed-fp32-ops: no v_pk_{mul,add,fma}_f32.  On gfx950 a packed f32 op costs the VALU port 8 cycles -- the same as the two scalar ops it
+# replaces -- and beside MFMAs it stalls the matrix pipe on top (scratch/r3/coissue*.hip: 2 v_pk_fma_f32 per 32x32x16 MFMA = 60 cycles per
+# MFMA against 36 with 2 v_fma_f32).  hipcc forms them from every float4 / float2 expression.  Same-box A/B of the whole step: +1.2 %
+# images/s (block kernels -1.5 ... -3 %); profiles/r03a_nopk_ab.txt.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+         "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 
 
 def _hipcc() -> str:
@@ -29,9 +34,11 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, extra_flags=(), lib_path: str = LIB, objdir_name: str = "build") -> str:
+    """extra_flags / lib_path / objdir_name: a second build of the same ABI next to the product one (same-box A/B of compiler
+    options or kernel variants; load it with CHADAVIT_HIP_LIB)."""
     hipcc = _hipcc()
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, objdir_name)
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, "common.h"), os.path.join(ROOT, "include", "chadavit_hip.h")]
     jobs = []
@@ -42,7 +49,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         objs.append(op)
         deps = [sp] + headers + ([os.path.join(CSRC, "ffn_fused.hip")] if src == "ffn_fused_d384.hip" else [])
         if force or _stale(op, deps):
-            jobs.append([hipcc, *FLAGS, "-c", sp, "-o", op])
+            jobs.append([hipcc, *FLAGS, *extra_flags, "-c", sp, "-o", op])
 
     def run(cmd):
         if verbose:
@@ -55,9 +62,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
-    if force or jobs or _stale(LIB, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
-    return LIB
+    if force or jobs or _stale(lib_path, objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path, *objs])
+    return lib_path
 
 
 if __name__ == "__main__":

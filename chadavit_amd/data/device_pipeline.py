@@ -37,11 +37,12 @@ class CropSpec:
     rrc_enabled: bool = True
     crop_min_scale: float = 0.25
     crop_max_scale: float = 1.0
-    jitter_prob: float = 0.0
+    jitter_prob: float = 0.0            # NON-ZERO = the jitter is applied to EVERY crop (see _draw); the value itself is never drawn against
     int_min_shift: float = -0.3
     int_max_shift: float = 0.3
     gamma_min: float = 0.5
     gamma_max: float = 1.5
+    gray_prob: float = 0.0              # A.ToGray(p): 3-channel samples only (anything else raises when it fires, as in albumentations)
     blur_prob: float = 0.0
     blur_limit: Tuple[int, int] = (3, 7)
     sigma_limit: Tuple[float, float] = (0.1, 2.0)
@@ -50,20 +51,26 @@ class CropSpec:
     solarize_max: float = 1.0           # MAX_VALUES_BY_DTYPE[float32]
     flip_prob: float = 0.0
     normalize: Optional[Tuple[Sequence[float], Sequence[float], float]] = None   # (mean per channel, std per channel, max_pixel_value)
+    normalize_prob: float = 1.0         # A.Normalize(..., p=cfg.normalize.prob) (pretrain_dataloader.py:322-323): drawn per sample
     ratio: Tuple[float, float] = (3.0 / 4.0, 4.0 / 3.0)
 
     @staticmethod
     def from_cfg(aug) -> "CropSpec":
         """From one node of the reference's `augmentations` cfg list (keys of pretrain_dataloader.py:232-255)."""
         g = lambda node, key, default: (node.get(key, default) if hasattr(node, "get") else getattr(node, key, default))
-        if g(g(aug, "grayscale", {}), "prob", 0) or g(g(aug, "equalization", {}), "prob", 0):
-            raise RuntimeError("ToGray / Equalize need 3-channel / uint8 images: not part of the channel-adaptive float path")
+        if g(g(aug, "equalization", {}), "prob", 0):
+            # albumentations' Equalize accepts uint8 images only ("Image must have uint8 channel type") and the IDRCell reader hands
+            # out float32 planes (custom_datasets.py:199-215): in the reference a firing Equalize raises.  Out of scope, loudly.
+            raise RuntimeError("equalization.prob > 0: A.Equalize needs uint8 images; the channel-adaptive path is float32 (the "
+                               "reference's own pipeline raises when it fires)")
         cj, rrc = g(aug, "color_jitter", {}), g(aug, "rrc", {})
         norm = g(aug, "normalize", None)
+        norm_prob = g(norm, "prob", 1.0) if norm and not isinstance(norm, bool) else 1.0
         return CropSpec(crop_size=g(aug, "crop_size", 224), num_crops=g(aug, "num_crops", 1), rrc_enabled=bool(g(rrc, "enabled", True)),
                         crop_min_scale=g(rrc, "crop_min_scale", 0.08), crop_max_scale=g(rrc, "crop_max_scale", 1.0),
                         jitter_prob=g(cj, "prob", 0.0), int_min_shift=g(cj, "int_min_shift", -0.3), int_max_shift=g(cj, "int_max_shift", 0.3),
                         gamma_min=g(cj, "gamma_min", 0.5), gamma_max=g(cj, "gamma_max", 1.5),
+                        gray_prob=g(g(aug, "grayscale", {}), "prob", 0.0), normalize_prob=float(norm_prob),
                         blur_prob=g(g(aug, "gaussian_blur", {}), "prob", 0.0), solarize_prob=g(g(aug, "solarization", {}), "prob", 0.0),
                         flip_prob=g(g(aug, "horizontal_flip", {}), "prob", 0.0),
                         normalize=(g(aug, "mean", None), g(aug, "std", None), 255.0) if norm and g(aug, "mean", None) is not None else None)
@@ -109,6 +116,8 @@ class CropParams:
     blurs: List[Optional[Tuple[int, float]]] = field(default_factory=list)   # per image (ksize, sigma) or None
     solarize: List[Optional[float]] = field(default_factory=list)            # per image threshold or None
     flips: List[bool] = field(default_factory=list)
+    grays: List[bool] = field(default_factory=list)                          # per image: ToGray fired
+    normalized: List[bool] = field(default_factory=list)                     # per image: Normalize fired (p = normalize_prob)
 
 
 class DeviceMultiCropPipeline:
@@ -124,15 +133,25 @@ class DeviceMultiCropPipeline:
         return sum(s.num_crops for s in self.specs)
 
     def _draw(self, spec: CropSpec, shapes: Sequence[Tuple[int, int, int]]) -> CropParams:
+        """The random parameters of one crop of every sample, drawn in the order albumentations 1.3.1 consumes Python's `random`
+        inside `Compose.__call__` for the reference's list (pretrain_dataloader.py:281-326).  Every `BasicTransform.__call__`
+        evaluates `random.random() < p` first -- also for p = 1.0 and for always_apply transforms (ToTensorV2) --, EXCEPT the
+        reference's own `CustomColorJitter`: it overrides `__call__` (custom_transforms.py:309-311) and calls `apply` directly, so
+        its `p` is never consulted and no draw is consumed: with `color_jitter.prob` non-zero EVERY crop is jittered (the
+        shipped 0.8 behaves as 1.0).  Reproduced as is."""
         p = CropParams()
         for (C, H, W) in shapes:
             self.rng.random()  # RandomResizedCrop / Resize: p = 1.0, the draw still happens (BasicTransform.__call__)
             p.boxes.append(rrc_box(H, W, (spec.crop_min_scale, spec.crop_max_scale), spec.ratio, self.rng) if spec.rrc_enabled else (0, 0, H, W))
-            if spec.jitter_prob and self.rng.random() < spec.jitter_prob:
+            if spec.jitter_prob:   # in the list at all <=> prob != 0 (pretrain_dataloader.py:301); then unconditional, no draw
                 p.shifts.append(self.np_rng.uniform(spec.int_min_shift, spec.int_max_shift, C))
                 p.gammas.append(self.np_rng.uniform(spec.gamma_min, spec.gamma_max, C))
             else:
                 p.shifts.append(None); p.gammas.append(None)
+            gray = bool(spec.gray_prob and self.rng.random() < spec.gray_prob)
+            if gray and C != 3:
+                raise RuntimeError(f"ToGray fired on a {C}-channel sample: albumentations raises TypeError there (3-channel images only)")
+            p.grays.append(gray)
             if spec.blur_prob and self.rng.random() < spec.blur_prob:
                 k = self.rng.randrange(spec.blur_limit[0], spec.blur_limit[1] + 1)
                 if k != 0 and k % 2 != 1:
@@ -145,6 +164,8 @@ class DeviceMultiCropPipeline:
             else:
                 p.solarize.append(None)
             p.flips.append(bool(spec.flip_prob and self.rng.random() < spec.flip_prob))
+            self.rng.random()  # ToTensorV2(always_apply=True): `random.random() < p or always_apply` still draws
+            p.normalized.append(bool(spec.normalize is not None and self.rng.random() < spec.normalize_prob))
         return p
 
     def __call__(self, images: Sequence[np.ndarray], labels: Optional[Sequence[int]] = None, params: Optional[List[CropParams]] = None):
@@ -183,7 +204,9 @@ class DeviceMultiCropPipeline:
         S = spec.crop_size
         desc, shift, gamma, fin = [], [], [], []
         any_jit = any(s is not None for s in cp.shifts)
-        any_fin = spec.normalize is not None or any(b is not None for b in cp.blurs) or any(t is not None for t in cp.solarize)
+        normed = cp.normalized if cp.normalized else [spec.normalize is not None] * len(shapes)
+        grays = cp.grays if cp.grays else [False] * len(shapes)
+        any_fin = any(normed) or any(b is not None for b in cp.blurs) or any(t is not None for t in cp.solarize)
         for i, (C, H, W) in enumerate(shapes):
             y0, x0, h, w = cp.boxes[i]
             for c in range(C):
@@ -201,7 +224,7 @@ class DeviceMultiCropPipeline:
                         row[1:8] = gaussian_taps(k, sg)
                     row[8] = np.inf if cp.solarize[i] is None else cp.solarize[i]
                     row[9] = spec.solarize_max
-                    if spec.normalize is not None:
+                    if normed[i]:
                         mean, std, mpv = spec.normalize
                         row[10] = float(mean[c % len(mean)]) * mpv
                         row[11] = 1.0 / (float(std[c % len(std)]) * mpv)
@@ -216,6 +239,16 @@ class DeviceMultiCropPipeline:
                                   out=first)
         else:
             res = ops.crop_resize(src, d, S, out=first)
+        if any(grays):
+            # A.ToGray on the (rare) 3-channel samples that drew it: cv2 RGB2GRAY weights, replicated to the three planes
+            # (albumentations functional.to_gray).  Sits between the jitter and the blur as in the reference's list; it commutes
+            # with the flip fused into the resize pass.  Plain tensor arithmetic on three planes per firing sample.
+            w = torch.tensor([0.299, 0.587, 0.114], device=dev, dtype=torch.float32).view(3, 1, 1, 1)
+            c0 = 0
+            for i, (C, H, W) in enumerate(shapes):
+                if grays[i]:
+                    res[c0:c0 + 3] = (res[c0:c0 + 3] * w).sum(0, keepdim=True)
+                c0 += C
         if any_fin:
             res = ops.blur_finish(res, torch.from_numpy(np.stack(fin)).to(dev), out=out)
         return res

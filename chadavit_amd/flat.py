@@ -201,6 +201,12 @@ class FlatParams:
             elif self._pk_desc is not None:
                 ops.ffn_pack_batched(self.bf16, self._pk_buf, self._pk_desc, len(self._pk_src), *self._pk_shape)
             self._cast_version = ver
+            # fp8 weight path: every weight that HAS an MX-fp8 copy is re-quantised here, eagerly, on the stream refresh() runs
+            # on (DINO.training_step calls it on the main stream before the side streams fork).  Left lazy, the first pass to
+            # ask re-quantised in place on ITS stream while a pass on another stream could still hit the cache and read the
+            # buffers half written.
+            for name in list(self._mx8):
+                self.mx8(name)
         if need_transposes and ver != self._cast_version_t:
             if self._t_desc is not None:
                 ops.cast_transpose_batched(self.flat, self._t_buf, self._t_desc, len(self.transpose_names), self._t_max_tiles)

@@ -41,23 +41,63 @@ class DINOLoss(nn.Module):
         if num_large_crops != 2:
             raise RuntimeError("DINOLoss: the reference loss is defined over exactly 2 global views (losses/dino.py:87)")
         self.register_buffer("center", torch.zeros(1, num_prototypes))
+        self._pending = None       # (event | work, column sum, 1 / (world * rows)) of a centre update in flight
+        self._comm_stream = None
         self.teacher_temp_schedule = np.concatenate((
             np.linspace(warmup_teacher_temp, teacher_temp, warmup_teacher_temp_epochs),
             np.ones(num_epochs - warmup_teacher_temp_epochs) * teacher_temp))
 
     def forward(self, student_output: torch.Tensor, teacher_output: torch.Tensor) -> torch.Tensor:
         temp = float(self.teacher_temp_schedule[self.epoch])
+        self.sync_center()  # the previous step's centre update (its all-reduce ran beside that step's backward)
         loss, colsum = _DinoLossFn.apply(student_output, teacher_output, self.center, float(self.student_temp), temp)
         self.update_center(teacher_output, colsum)
         return loss
 
     @torch.no_grad()
     def update_center(self, teacher_output: torch.Tensor, colsum: torch.Tensor = None):
-        """c <- m c + (1-m) * sum_rows(t) [all-reduce SUM] / world / rows   (losses/dino.py:103-118)."""
+        """c <- m c + (1-m) * sum_rows(t) [all-reduce SUM] / world / rows   (losses/dino.py:103-118).
+
+        The new centre is first read by the NEXT step's loss, so with several ranks the P-float all-reduce is
+        only STARTED here -- on the communication stream (RCCL) or as an asynchronous gloo work -- and `sync_center` finishes
+        the update (wait + the EMA kernel) right before the centre is read again: the collective is no rank rendezvous between
+        the loss and the backward, and the centre each rank ends up with is the one the blocking form produces."""
         if colsum is None:
             colsum = ops.sum_rows_f32(teacher_output.float().contiguous())
-        world = 1
-        if dist.is_available() and dist.is_initialized():
-            dist.all_reduce(colsum)
-            world = dist.get_world_size()
-        ops.center_ema(self.center.view(-1), colsum, 1.0 / (world * len(teacher_output)), float(self.center_momentum))
+        self.sync_center()
+        inv = 1.0 / len(teacher_output)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            inv /= dist.get_world_size()
+            if dist.get_backend() == "nccl":
+                main = torch.cuda.current_stream(colsum.device)
+                if self._comm_stream is None:
+                    self._comm_stream = torch.cuda.Stream(device=colsum.device)
+                self._comm_stream.wait_stream(main)  # the column sum is complete on the compute stream
+                with torch.cuda.stream(self._comm_stream):
+                    dist.all_reduce(colsum)
+                    done = torch.cuda.Event()
+                    done.record(self._comm_stream)
+                colsum.record_stream(self._comm_stream)
+                self._pending = (done, colsum, inv)
+            else:
+                self._pending = (dist.all_reduce(colsum, async_op=True), colsum, inv)
+            return
+        ops.center_ema(self.center.view(-1), colsum, inv, float(self.center_momentum))
+
+    @torch.no_grad()
+    def sync_center(self):
+        """Finish a centre update whose all-reduce is still in flight (no-op otherwise).  Called before every read of `center`
+        by this module (forward, state_dict); call it before reading the buffer directly."""
+        if self._pending is None:
+            return
+        done, colsum, inv = self._pending
+        self._pending = None
+        if isinstance(done, torch.cuda.Event):
+            torch.cuda.current_stream(colsum.device).wait_event(done)
+        else:
+            done.wait()
+        ops.center_ema(self.center.view(-1), colsum, inv, float(self.center_momentum))
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):  # (also reached through a parent module's state_dict())
+        self.sync_center()
+        super()._save_to_state_dict(destination, prefix, keep_vars)

@@ -28,6 +28,7 @@ from ..backbones.vit.chada_vit import ChAdaViT, trunc_normal_
 from ..data.channels_strategies import adjacent_view
 from ..flat import FlatParams
 from ..losses.dino import DINOLoss
+from ..ragged import ragged_batch
 from ..utils.misc import AttrDict, ensure_node, is_missing, omegaconf_select
 from ..utils.momentum import MomentumUpdater, initialize_momentum_params
 
@@ -40,13 +41,34 @@ except Exception:  # noqa: BLE001
         current_epoch: int = 0
         trainer: Any = None
 
-        def log(self, name, value, *a, **k):
+        def log(self, name, value, *a, sync_dist: bool = False, **k):
+            """Lightning's `self.log`.  sync_dist=True (dino.py:319: the training / validation loss) asks for the MEAN over
+            ranks; a collective per logged value and step would put a rank rendezvous into the step, so the value is kept as a
+            detached tensor and the reduction happens when the metrics are READ (`logged_metrics`): one all-reduce of all
+            sync_dist values, off the training path."""
             self._logged = getattr(self, "_logged", {})
-            self._logged[name] = value
+            self._logged_sync = getattr(self, "_logged_sync", set())
+            self._logged[name] = value.detach() if isinstance(value, torch.Tensor) else value
+            (self._logged_sync.add if sync_dist else self._logged_sync.discard)(name)
 
         def log_dict(self, d, *a, **k):
             for n, v in d.items():
-                self.log(n, v)
+                self.log(n, v, **k)
+
+        def logged_metrics(self) -> Dict[str, float]:
+            """Last logged value per name as floats; names logged with sync_dist=True are averaged over the ranks
+            (collective: every rank has to call it, as with Lightning's own reduction)."""
+            import torch.distributed as dist
+            vals = dict(getattr(self, "_logged", {}))
+            names = sorted(n for n in getattr(self, "_logged_sync", ()) if n in vals)
+            if names and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                dev = next((vals[n].device for n in names if isinstance(vals[n], torch.Tensor)), torch.device("cpu"))
+                t = torch.stack([torch.as_tensor(vals[n], dtype=torch.float64, device=dev).reshape(()) for n in names])
+                dist.all_reduce(t)
+                t /= dist.get_world_size()
+                for n, v in zip(names, t.tolist()):
+                    vals[n] = v
+            return {n: (float(v) if isinstance(v, (torch.Tensor, int, float)) else v) for n, v in vals.items()}
 
 
 # ==============================================================================================
@@ -424,14 +446,17 @@ class DINO(_Base):
             if xg is None:
                 xg = torch.cat(list(X[:nl]), dim=0)
             nch = [c for k in range(nl) for c in list_num_channels[k]]
+            # ONE description of the global-crop batch, uploaded on the main stream before the fork; both passes take it (a
+            # side-stream consumer orders itself behind the upload: RaggedBatch.use_on_current_stream)
+            rbg = ragged_batch(nch, (xg.shape[-1] // self.backbone.token_learner.patch_size) ** 2, xg.device)
             if use_streams:
                 # after the cat above (and after the previous step's optimiser / EMA, all enqueued on `main`)
                 s_teacher.wait_stream(main)
                 s_local.wait_stream(main)
                 xg.record_stream(s_teacher)
                 with torch.cuda.stream(s_teacher), torch.no_grad():
-                    momentum_p = self.momentum_head(self.momentum_backbone.forward_ragged(xg, nch))
-            feats = self.backbone.forward_ragged(xg, nch)
+                    momentum_p = self.momentum_head(self.momentum_backbone.forward_ragged(xg, nch, rb=rbg))
+            feats = self.backbone.forward_ragged(xg, nch, rb=rbg)
             p = self.head(feats)
             feats_list = list(feats.chunk(nl))
             if use_streams:
@@ -439,7 +464,7 @@ class DINO(_Base):
                 momentum_p.record_stream(main)
             else:
                 with torch.no_grad():
-                    momentum_p = self.momentum_head(self.momentum_backbone.forward_ragged(xg, nch))
+                    momentum_p = self.momentum_head(self.momentum_backbone.forward_ragged(xg, nch, rb=rbg))
         else:
             outs = [self(x, k) for k, x in enumerate(X[:nl])]
             p = torch.cat([o["z"] for o in outs])

@@ -55,6 +55,13 @@ class SpanAllReduce:
         self._works: List = []
         self.spans: List[Tuple[int, int]] = []
         self.bytes = 0
+        # timing=True (bench.py): per step, HIP events on both streams around the hand-over in finish() -- how long the compute
+        # stream had to WAIT for the last collective (= communication not hidden behind the backward) and how long the
+        # communication stream was busy from its first collective on
+        self.timing = False
+        self._first_ev = None
+        self._timed: List = []
+        self._host_wait_s: List[float] = []
 
     def _comm_stream(self, device):
         if self._stream is None:
@@ -71,6 +78,9 @@ class SpanAllReduce:
             cs = self._comm_stream(chunk.device)
             cs.wait_stream(torch.cuda.current_stream(chunk.device))  # span is final on the compute stream
             with torch.cuda.stream(cs):
+                if self.timing and self._first_ev is None:
+                    self._first_ev = torch.cuda.Event(enable_timing=True)
+                    self._first_ev.record(cs)
                 if self.native_avg:
                     dist.all_reduce(chunk, op=dist.ReduceOp.AVG, group=self.group)
                 else:
@@ -83,11 +93,40 @@ class SpanAllReduce:
     def finish(self, device=None):
         """Make the averaged gradients visible to the compute stream / host."""
         if self._stream is not None:
-            torch.cuda.current_stream(device).wait_stream(self._stream)
-        for w, chunk in self._works:
-            w.wait()
-            chunk.div_(self.world)
+            main = torch.cuda.current_stream(device)
+            if self.timing and self._first_ev is not None:
+                ready, done = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ready.record(main)          # the backward's own work ends here ...
+                done.record(self._stream)   # ... the last collective here
+                self._timed.append((self._first_ev, ready, done))
+                self._first_ev = None
+            main.wait_stream(self._stream)
+        if self._works:
+            import time
+            t0 = time.perf_counter()
+            for w, chunk in self._works:
+                w.wait()
+                chunk.div_(self.world)
+            if self.timing:
+                self._host_wait_s.append(time.perf_counter() - t0)
         self._works = []
+
+    def timing_summary(self) -> Optional[dict]:
+        """After a device synchronize: {"exposed_ms_per_step", "comm_busy_ms_per_step", "steps"} over the timed steps."""
+        if self._timed:
+            exp = [max(0.0, ready.elapsed_time(done)) for _, ready, done in self._timed]
+            busy = [first.elapsed_time(done) for first, _, done in self._timed]
+            n = len(exp)
+            self._timed = []
+            return {"exposed_ms_per_step": round(sum(exp) / n, 4), "exposed_ms_max": round(max(exp), 4),
+                    "comm_busy_ms_per_step": round(sum(busy) / n, 4), "steps": n}
+        if self._host_wait_s:
+            n = len(self._host_wait_s)
+            out = {"exposed_ms_per_step": round(1e3 * sum(self._host_wait_s) / n, 4), "exposed_ms_max": round(1e3 * max(self._host_wait_s), 4),
+                   "comm_busy_ms_per_step": None, "steps": n}
+            self._host_wait_s = []
+            return out
+        return None
 
     def reset_stats(self):
         self.spans, self.bytes = [], 0

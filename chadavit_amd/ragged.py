@@ -49,6 +49,17 @@ class RaggedBatch:
         if torch.device(device).type == "cuda":
             host = host.pin_memory()
         dev = host.to(device, non_blocking=True)
+        # The upload is enqueued on whatever stream is current HERE.  Consumers on another stream (the teacher / local-crop side
+        # streams of DINO.training_step share one description with the student pass) must order themselves behind it: `ready`
+        # is recorded right after the copy and `use_on_current_stream` waits for it and tells the caching allocator about the
+        # extra reader, so neither the copy nor a later re-issue of the buffer can race a kernel that still reads the indices.
+        self._dev = dev
+        self._alloc_stream = None
+        self.ready = None
+        if dev.is_cuda:
+            self._alloc_stream = torch.cuda.current_stream(dev.device)
+            self.ready = torch.cuda.Event()
+            self.ready.record(self._alloc_stream)
         o = 0
         self.cu_seqlens = dev[o:o + self.B + 1]; o += self.B + 1
         self.work = dev[o:o + 2 * self.n_work].view(self.n_work, 2); o += 2 * self.n_work
@@ -60,6 +71,15 @@ class RaggedBatch:
     @property
     def host_cu_seqlens(self) -> List[int]:
         return self._host_cu
+
+    def use_on_current_stream(self) -> "RaggedBatch":
+        """Make the index arrays safe to read from kernels launched on the CURRENT stream (no-op on the uploading stream)."""
+        if self.ready is not None:
+            cur = torch.cuda.current_stream(self._dev.device)
+            if cur != self._alloc_stream:
+                cur.wait_event(self.ready)
+                self._dev.record_stream(cur)
+        return self
 
 
 # The student and the teacher pass of one step (and every step of a fixed-channel dataset) describe the same batch: the index
@@ -76,5 +96,5 @@ def ragged_batch(num_channels: Sequence[int], patches_per_channel: int, device) 
         while len(_CACHE) >= _CACHE_MAX:
             _CACHE.pop(next(iter(_CACHE)))
     _CACHE[key] = rb   # most recently used last
-    return rb
+    return rb.use_on_current_stream()
 

@@ -5,7 +5,12 @@ albumentations 1.3.1 / opencv-python 4.7.0.72 transforms (pinned in pyproject.to
 `CustomColorJitter` (src/data/custom_transforms.py:301-351):
 
     RandomResizedCrop(INTER_CUBIC) | Resize(INTER_CUBIC) -> CustomColorJitter -> [ToGray] -> GaussianBlur(sigma 0.1..2) ->
-    Solarize -> [Equalize] -> HorizontalFlip -> ToTensorV2 -> Normalize
+    Solarize -> [Equalize] -> HorizontalFlip -> ToTensorV2 -> Normalize(p)
+
+Gating (albumentations `BasicTransform.__call__`: `random.random() < p` per transform and sample, drawn even for p = 1 and for
+always_apply transforms) -- with ONE exception owned by the reference: `CustomColorJitter` overrides `__call__`
+(custom_transforms.py:309-311) and applies unconditionally without a draw, so a non-zero `color_jitter.prob` jitters every crop.
+`draw_order()` below states the sequence of `random` draws per sample; chadavit_amd/data/device_pipeline.py::_draw follows it.
 
 Neither albumentations nor OpenCV is installed in this image, so **parity of this file is UNPINNED by the
 third-party code itself**; each function restates the PUBLISHED algorithm of the pinned version and is anchored by
@@ -125,6 +130,31 @@ def color_jitter(plane: np.ndarray, shift: float, gamma: float) -> np.ndarray:
     return np.clip(np.float32(gamma) * (np.asarray(plane, dtype=np.float32) + np.float32(shift)), 0.0, 1.0).astype(np.float32)
 
 
+def draw_order(jitter: bool, gray: bool, blur: bool, solarize: bool, flip: bool, normalize: bool) -> List[str]:
+    """Names of the Python-`random` draws one sample consumes, in order, for a list built by build_transform_pipeline
+    (a transform is in the list iff its cfg prob is non-zero; the crop / ToTensorV2 always are).  The jitter never draws from
+    `random` (its parameters come from numpy's global RNG inside `apply`)."""
+    seq = ["crop:p", "crop:params..."]
+    if gray:
+        seq.append("gray:p")
+    if blur:
+        seq += ["blur:p", "blur:ksize,sigma (if fired)"]
+    if solarize:
+        seq += ["solarize:p", "solarize:threshold (if fired)"]
+    if flip:
+        seq.append("flip:p")
+    seq.append("to_tensor:p")
+    if normalize:
+        seq.append("normalize:p")
+    return seq
+
+
+def to_gray(planes: np.ndarray) -> np.ndarray:
+    """albumentations.ToGray on a (3, H, W) float image: cv2.cvtColor RGB2GRAY (0.299, 0.587, 0.114) then GRAY2RGB."""
+    g = (np.float32(0.299) * planes[0] + np.float32(0.587) * planes[1] + np.float32(0.114) * planes[2]).astype(np.float32)
+    return np.stack([g, g, g])
+
+
 def augment_plane(plane: np.ndarray, S: int, box: Tuple[int, int, int, int], shift: Optional[float] = None, gamma: Optional[float] = None,
                   flip: bool = False, blur: Optional[Tuple[int, float]] = None, sol_threshold: Optional[float] = None,
                   norm: Optional[Tuple[float, float, float]] = None) -> np.ndarray:
@@ -142,3 +172,32 @@ def augment_plane(plane: np.ndarray, S: int, box: Tuple[int, int, int, int], shi
     if norm is not None:
         out = normalize(out, *norm)
     return np.ascontiguousarray(out, dtype=np.float32)
+
+
+def augment_sample(planes: np.ndarray, S: int, box: Tuple[int, int, int, int], shifts=None, gammas=None, gray: bool = False,
+                   flip: bool = False, blur: Optional[Tuple[int, float]] = None, sol_threshold: Optional[float] = None,
+                   norms: Optional[Sequence[Tuple[float, float, float]]] = None) -> np.ndarray:
+    """All channels of one sample through the chain, including the one step that mixes channels (ToGray, 3-channel samples):
+    resize -> jitter (per channel) -> [gray] -> blur -> solarize -> flip -> [normalize (per channel)]."""
+    y0, x0, h, w = box
+    C = planes.shape[0]
+    out = np.stack([resize_cubic(planes[c][y0:y0 + h, x0:x0 + w], S) for c in range(C)])
+    if shifts is not None:
+        out = np.stack([color_jitter(out[c], shifts[c], gammas[c]) for c in range(C)])
+    if gray:
+        assert C == 3, "ToGray is defined for 3-channel images only"
+        out = to_gray(out)
+    res = []
+    for c in range(C):
+        o = out[c]
+        if blur is not None:
+            o = gaussian_blur(o, blur[0], blur[1])
+        if sol_threshold is not None:
+            o = solarize(o, sol_threshold)
+        if flip:
+            o = o[:, ::-1]
+        if norms is not None:
+            o = normalize(o, *norms[c])
+        res.append(np.ascontiguousarray(o, dtype=np.float32))
+    return np.stack(res)
+

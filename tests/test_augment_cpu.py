@@ -67,6 +67,54 @@ def test_pointwise_steps():
     # the reference-owned jitter itself is pinned by tests/golden/jitter.npz (tests/test_oracle_golden.py)
 
 
+def test_gating_and_draw_order_of_the_host_side_draws():
+    """The reference's CustomColorJitter overrides __call__ (custom_transforms.py:309-311): applied to EVERY crop once it is in the
+    list, no Python-`random` draw; every albumentations transform draws `random.random() < p` per sample, ToTensorV2 included;
+    A.Normalize honours its p (pretrain_dataloader.py:322-323)."""
+    from chadavit_amd.data.device_pipeline import CropSpec, DeviceMultiCropPipeline
+
+    class Counting(random.Random):
+        def __init__(self, seed):
+            super().__init__(seed)
+            self.n = 0
+
+        def random(self):
+            self.n += 1
+            return super().random()
+
+    shapes = [(3, 64, 64)] * 200
+    # jitter only: crop p + ToTensor p per sample, plus the crop's own parameter draws -- the jitter adds none
+    a = DeviceMultiCropPipeline([CropSpec(crop_size=32, jitter_prob=0.8, rrc_enabled=False)], "cpu", seed=1)
+    b = DeviceMultiCropPipeline([CropSpec(crop_size=32, jitter_prob=0.0, rrc_enabled=False)], "cpu", seed=1)
+    a.rng, b.rng = Counting(1), Counting(1)
+    pa, pb = a._draw(a.specs[0], shapes), b._draw(b.specs[0], shapes)
+    assert a.rng.n == b.rng.n == 2 * len(shapes)
+    assert all(s is not None for s in pa.shifts) and all(s is None for s in pb.shifts)
+    assert all(g.shape == (3,) and (0.5 <= g).all() and (g <= 1.5).all() for g in pa.gammas)
+    # normalize.prob: fires for about that fraction of the samples, one extra draw each; gray likewise
+    c = DeviceMultiCropPipeline([CropSpec(crop_size=32, rrc_enabled=False, gray_prob=0.3, normalize=([0.5], [0.25], 1.0), normalize_prob=0.25)],
+                                "cpu", seed=2)
+    c.rng = Counting(2)
+    pc = c._draw(c.specs[0], shapes)
+    assert c.rng.n == 4 * len(shapes)
+    assert 0.15 < sum(pc.normalized) / len(shapes) < 0.35 and 0.2 < sum(pc.grays) / len(shapes) < 0.4
+    assert A.draw_order(True, True, False, False, False, True) == ["crop:p", "crop:params...", "gray:p", "to_tensor:p", "normalize:p"]
+    # cfg mapping (keys of pretrain_dataloader.py:232-255)
+    aug = {"crop_size": 96, "num_crops": 2, "rrc": {"enabled": True, "crop_min_scale": 0.05, "crop_max_scale": 0.25},
+           "color_jitter": {"prob": 0.8, "int_min_shift": -0.2, "int_max_shift": 0.2, "gamma_min": 0.7, "gamma_max": 1.3},
+           "grayscale": {"prob": 0.2}, "gaussian_blur": {"prob": 0.1}, "solarization": {"prob": 0.2}, "equalization": {"prob": 0.0},
+           "horizontal_flip": {"prob": 0.5}, "normalize": {"prob": 0.7}, "mean": [0.1, 0.2], "std": [0.3, 0.4]}
+    sp = CropSpec.from_cfg(aug)
+    assert (sp.gray_prob, sp.normalize_prob, sp.jitter_prob, sp.blur_prob, sp.flip_prob) == (0.2, 0.7, 0.8, 0.1, 0.5)
+    assert sp.normalize == ([0.1, 0.2], [0.3, 0.4], 255.0)
+    with pytest.raises(RuntimeError, match="Equalize needs uint8"):
+        CropSpec.from_cfg(dict(aug, equalization={"prob": 0.1}))
+    x = np.random.RandomState(0).rand(3, 5, 5).astype(np.float32)
+    g = A.to_gray(x)
+    np.testing.assert_allclose(g[1], 0.299 * x[0] + 0.587 * x[1] + 0.114 * x[2], atol=1e-6)
+    assert np.array_equal(g[0], g[2])
+
+
 def test_rrc_parameter_draws():
     """Host-side draws of the device pipeline == the oracle's restatement for the same seed; boxes are inside the image, the area
     fraction is in `scale`, aspect ratio in [3/4, 4/3] up to integer rounding."""

@@ -22,14 +22,14 @@ def test_device_multicrop_matches_oracle_and_collate_layout():
     dev = torch.device("cuda:0")
     imgs = _batch()
     specs = [CropSpec(crop_size=224, num_crops=2, crop_min_scale=0.25, crop_max_scale=1.0, jitter_prob=0.8, blur_prob=0.7, solarize_prob=0.5,
-                      solarize_threshold=0.6, flip_prob=0.5, normalize=([0.4, 0.5, 0.6], [0.2, 0.25, 0.3], 1.0)),
+                      solarize_threshold=0.6, flip_prob=0.5, normalize=([0.4, 0.5, 0.6], [0.2, 0.25, 0.3], 1.0), normalize_prob=0.6),
              CropSpec(crop_size=96, num_crops=3, crop_min_scale=0.05, crop_max_scale=0.25, jitter_prob=0.8, blur_prob=0.5, flip_prob=0.5),
              CropSpec(crop_size=224, num_crops=1, rrc_enabled=False)]   # plain Resize branch (pretrain_dataloader.py:292-299)
     pipe = DeviceMultiCropPipeline(specs, dev, seed=3)
     crops, labels, ncl = pipe(imgs, labels=[0, 1, 2, 3, 4])
     assert len(crops) == 6 and [tuple(c.shape) for c in crops] == [(21, 1, 224, 224)] * 2 + [(21, 1, 96, 96)] * 3 + [(21, 1, 224, 224)]
     assert ncl == [[3, 1, 5, 10, 2]] * 6 and labels.tolist() == [0, 1, 2, 3, 4]
-    drew = {"jit": 0, "blur": 0, "sol": 0, "flip": 0}
+    drew = {"jit": 0, "blur": 0, "sol": 0, "flip": 0, "norm": 0, "nonorm": 0}
     k = 0
     for spec in specs:
         for _ in range(spec.num_crops):
@@ -38,7 +38,7 @@ def test_device_multicrop_matches_oracle_and_collate_layout():
             for i, im in enumerate(imgs):
                 for c in range(im.shape[0]):
                     norm = None
-                    if spec.normalize is not None:
+                    if cp.normalized[i]:
                         mean, std, mpv = spec.normalize
                         norm = (mean[c % 3], std[c % 3], mpv)
                     ref_planes.append(A.augment_plane(im[c], spec.crop_size, cp.boxes[i],
@@ -47,6 +47,10 @@ def test_device_multicrop_matches_oracle_and_collate_layout():
                                                       cp.solarize[i], norm))
                 drew["jit"] += cp.shifts[i] is not None; drew["blur"] += cp.blurs[i] is not None
                 drew["sol"] += cp.solarize[i] is not None; drew["flip"] += cp.flips[i]
+                if spec.normalize is not None:
+                    drew["norm"] += cp.normalized[i]; drew["nonorm"] += not cp.normalized[i]
+                # CustomColorJitter ignores its p (custom_transforms.py:309-311): in the list <=> applied to every crop
+                assert (cp.shifts[i] is not None) == bool(spec.jitter_prob)
             ref = np.stack(ref_planes)[:, None]
             got = crops[k].cpu().numpy()
             # solarize is discontinuous: a value within round-off of the threshold may land on the other side -> compare away from it
@@ -66,6 +70,49 @@ def test_device_multicrop_matches_oracle_and_collate_layout():
         off += im.shape[0]
     cc, _, ncl2 = R.collate(per_image)
     assert ncl2 == ncl and all(torch.equal(a, b.cpu()) for a, b in zip(cc, crops))
+
+
+def test_gray_and_draw_order_on_three_channel_samples():
+    """A.ToGray (pretrain_dataloader.py:303-304) on 3-channel samples, between the jitter and the blur; it raises on any other
+    channel count when it fires, as albumentations does.  Also pins the number of Python-`random` draws per sample against the
+    oracle's statement of albumentations' order (jitter: none)."""
+    import random
+    from chadavit_amd.data.device_pipeline import CropSpec, DeviceMultiCropPipeline
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(4)
+    imgs = [rs.rand(3, 120 + 7 * i, 131).astype(np.float32) for i in range(6)]
+    spec = CropSpec(crop_size=96, num_crops=2, jitter_prob=0.8, gray_prob=0.5, blur_prob=0.5, flip_prob=0.5,
+                    normalize=([0.4, 0.5, 0.6], [0.2, 0.25, 0.3], 1.0), normalize_prob=0.5)
+    pipe = DeviceMultiCropPipeline([spec], dev, seed=9)
+    crops, _, _ = pipe(imgs)
+    fired = 0
+    for k in range(2):
+        cp = pipe.last_params[k]
+        ref = []
+        for i, im in enumerate(imgs):
+            norms = [(spec.normalize[0][c], spec.normalize[1][c], 1.0) for c in range(3)] if cp.normalized[i] else None
+            ref.append(A.augment_sample(im, 96, cp.boxes[i], cp.shifts[i], cp.gammas[i], cp.grays[i], cp.flips[i], cp.blurs[i], None, norms))
+            fired += cp.grays[i]
+            if cp.grays[i] and not cp.normalized[i]:
+                got = crops[k][3 * i:3 * i + 3, 0]
+                assert torch.equal(got[0], got[1]) and torch.equal(got[1], got[2])
+        np.testing.assert_allclose(crops[k][:, 0].cpu().numpy(), np.concatenate(ref), atol=1e-4, rtol=0)
+    assert 0 < fired < 12
+    # replaying the host draws with a counting RNG: per sample = crop p + crop params + gray p + blur p (+2) + flip p + ToTensor p
+    # + normalize p -- and nothing for the jitter
+    class Counting(random.Random):
+        n = 0
+        def random(self):
+            Counting.n += 1
+            return super().random()
+    pipe2 = DeviceMultiCropPipeline([spec], dev, seed=9)
+    pipe2.rng = Counting(9)
+    cp = pipe2._draw(spec, [(3, 64, 64)])
+    fixed = len([d for d in A.draw_order(True, True, True, False, True, True) if d.endswith(":p")])
+    assert fixed == 6 and Counting.n >= fixed
+    with pytest.raises(RuntimeError, match="ToGray fired"):
+        p3 = DeviceMultiCropPipeline([CropSpec(crop_size=96, num_crops=1, gray_prob=1.0)], dev, seed=0)
+        p3([rs.rand(5, 64, 64).astype(np.float32)])
 
 
 def test_pipeline_feeds_the_training_step():

@@ -489,6 +489,11 @@ def test_flat_param_kernels():
     _close(grads, ref, 1e-5, 1e-6, "clip")
     x = _rand((37, 5000), 34).to(dev)
     _close(ops.sum_rows_f32(x, 0.5), x.sum(0) * 0.5, 1e-5, 1e-5, "sum_rows")
+    # the centre's shapes (2B x P: 2-D decomposition, eight loads in flight per row group) and the scalar path (cols % 4 != 0)
+    for rows, cols in ((1024, 4096), (2048, 4096), (130, 65536), (300, 1027), (3, 64)):
+        x = _rand((rows, cols), 35).to(dev)
+        _close(ops.sum_rows_f32(x), x.double().sum(0).float(), 1e-5, 2e-4, f"sum_rows {rows}x{cols}")
+        assert torch.equal(ops.sum_rows_f32(x), ops.sum_rows_f32(x)), "sum_rows must be deterministic"
 
 
 def test_layernorm_fwd2_is_two_layernorms():

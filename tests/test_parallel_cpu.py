@@ -24,6 +24,7 @@ def _worker(rank, world, port, q):
     n = 1000
     flat = torch.arange(n, dtype=torch.float32) * (rank + 1)
     red = SpanAllReduce()
+    red.timing = True
     # spans fired in backward order (last block first), with a gap that must stay untouched
     for b, e in ((800, 1000), (400, 800), (64, 400)):
         red.submit(flat, b, e)
@@ -35,6 +36,16 @@ def _worker(rank, world, port, q):
     cs = torch.full((8,), float(rank + 1))
     dist.all_reduce(cs)
     ok = ok and torch.allclose(cs / world, torch.full((8,), sum(range(1, world + 1)) / world))
+    # bench.py's rccl.exposed_ms_per_step on the CPU path: host time blocked on the async works
+    ts = red.timing_summary()
+    ok = ok and ts is not None and ts["steps"] == 1 and ts["exposed_ms_per_step"] >= 0 and red.timing_summary() is None
+    # self.log(..., sync_dist=True) (dino.py:319): the value READ from the log is the mean over ranks
+    from chadavit_amd.methods.dino import _Base
+    m = _Base()
+    m.log("dino_loss_train", torch.tensor(float(rank + 1)), on_step=True, sync_dist=True)
+    m.log("tau", 0.5 + rank)  # not synced: stays rank-local
+    got = m.logged_metrics()
+    ok = ok and abs(got["dino_loss_train"] - sum(range(1, world + 1)) / world) < 1e-12 and got["tau"] == 0.5 + rank
     q.put((rank, bool(ok), red.bytes))
     dist.destroy_process_group()
 
