@@ -71,6 +71,10 @@ def parse():
                     "before the timed region: loss and gradient norm of the N-rank data-parallel step vs the same GLOBAL batch run by "
                     "one rank alone (rel <= 3e-2)")
     ap.add_argument("--no-verify-equal-batch", action="store_true", help="skip that self-check (two small extra steps per rank)")
+    ap.add_argument("--data", default="resident", choices=["resident", "pipeline"], help="pipeline: after the headline measurement (inputs "
+                    "resident in HBM, the contract's `value`) also measure the SURVEY 8(f)2 data path -- reader -> pinned staging -> H2D -> "
+                    "crop / jitter / blur kernels on a side stream (DevicePrefetcher) -- alone and feeding the same training step; reported as "
+                    "config.data_path, never as `value`")
     ap.add_argument("--no-other-workloads", action="store_true", help="N = 1 only: skip the short cfg3 / cfg5 legs run after the "
                     "headline measurement (reported as config.other_workloads)")
     ap.add_argument("--overlap", action="store_true", help="force the teacher / local-crop / dW side streams on (default: on for "
@@ -640,6 +644,86 @@ def other_workload_leg(name, args, dev, steps=3, warmup=2):
     return res
 
 
+def data_path_leg(wl, args, dev, tr, steps=6, n_samples=1536, side=256, workers=32):
+    """SURVEY 8(f)2 throughput: can the device data path feed the step?  Synthetic raw planes (C x side x side float32, the channel
+    mix of the workload) held in host memory stand for decoded images; the decode itself is timed separately on a small on-disk
+    IDRCell100k-format set (PNG, one file per channel).  Three numbers: decode images/s per reader thread, the pipeline alone
+    (H2D + kernels, prefetcher drained without a consumer), and the training step fed by the prefetcher."""
+    import tempfile
+    import numpy as np
+    import torch
+    from PIL import Image
+    from chadavit_amd.data.device_pipeline import CropSpec, DeviceMultiCropPipeline
+    from chadavit_amd.data.idrcell import IDRCell100K
+    from chadavit_amd.data.loader import DevicePrefetcher, InMemoryPlanes
+    B = wl["batch"]
+    rs = np.random.RandomState(0)
+    nch = channel_list(wl["channels"], n_samples, seed=7)
+    pool = [rs.rand(c, side, side).astype(np.float32) for c in sorted(set(nch))]   # one array per channel count, shared by the samples
+    by_c = {p.shape[0]: p for p in pool}
+    ds = InMemoryPlanes([by_c[c] for c in nch])
+    # the reference's asymmetric DINO augmentation (scripts/*/augmentations/asymmetric.yaml): jitter, blur 1.0 / 0.1, solarize 0 / 0.2, flip
+    specs = [CropSpec(crop_size=224, num_crops=1, crop_min_scale=0.25, crop_max_scale=1.0, jitter_prob=0.8, blur_prob=1.0, flip_prob=0.5),
+             CropSpec(crop_size=224, num_crops=1, crop_min_scale=0.25, crop_max_scale=1.0, jitter_prob=0.8, blur_prob=0.1, solarize_prob=0.2, flip_prob=0.5)]
+    if wl["n_local"]:
+        specs.append(CropSpec(crop_size=96, num_crops=wl["n_local"], crop_min_scale=0.05, crop_max_scale=0.25, jitter_prob=0.8, blur_prob=0.5, flip_prob=0.5))
+    batches = [list(range(i, i + B)) for i in range(0, n_samples - B + 1, B)]
+
+    def loader():
+        return DevicePrefetcher(ds, batches * ((steps + 2 + len(batches) - 1) // len(batches)), DeviceMultiCropPipeline(specs, dev, seed=1), depth=2, workers=workers)
+
+    # (a) pipeline alone
+    torch.cuda.synchronize()
+    n = 0
+    t0 = None
+    for i, batch in enumerate(loader()):
+        if i == 1:
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+        if i >= 1:
+            n += B
+        if i == steps:
+            break
+    torch.cuda.synchronize()
+    pipe_ips = (n - B) / (time.perf_counter() - t0) if n > B else None
+    # (b) the training step fed by it (the global crops arrive as two specs: adjacent_view falls back to one torch.cat)
+    n = 0
+    for i, batch in enumerate(loader()):
+        if i == 2:
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+        tr.train_step(batch, 10_000 + i)
+        if i >= 2:
+            n += B
+        if i == steps + 1:
+            break
+    torch.cuda.synchronize()
+    step_ips = n / (time.perf_counter() - t0)
+    # (c) decode rate of one reader thread on an on-disk set (8-bit PNG planes, `side` x `side`)
+    with tempfile.TemporaryDirectory(prefix="chadavit_idr_") as root:
+        os.makedirs(os.path.join(root, "images"))
+        with open(os.path.join(root, "train.csv"), "w") as f:
+            for i in range(48):
+                paths = []
+                for ch in range(3):
+                    rel = f"img{i}_ch{ch}.png"
+                    Image.fromarray(rs.randint(0, 255, size=(side, side), dtype=np.uint8)).save(os.path.join(root, "images", rel))
+                    paths.append(rel)
+                f.write(f'id{i},"{paths}"\n')
+        dsk = IDRCell100K(root_dir=root, train=True)
+        for i in range(8):
+            dsk.read_planes(i)
+        t0 = time.perf_counter()
+        for i in range(48):
+            dsk.read_planes(i)
+        decode_ips = 48 / (time.perf_counter() - t0)
+    raw_mb = sum(c * side * side * 4 for c in nch[:B]) / B / 1e6
+    return {"what": "reader threads -> pinned staging ring -> H2D -> chadavit_crop_resize / chadavit_blur_finish on a side stream (DevicePrefetcher), "
+                    "synthetic decoded planes in host memory", "raw_plane_side": side, "raw_MB_per_image": round(raw_mb, 2), "reader_threads": workers,
+            "pipeline_alone_images_per_s": None if pipe_ips is None else round(pipe_ips, 1), "step_fed_by_pipeline_images_per_s": round(step_ips, 1),
+            "h2d_GBps_at_that_rate": round(step_ips * raw_mb / 1e3, 2),
+            "decode_images_per_s_per_reader_thread": round(decode_ips, 1), "decode_format": f"3 x {side}x{side} 8-bit PNG per image (PIL)",
+            "reader_threads_needed_for_the_step": int(math.ceil(step_ips / decode_ips))}
+
+
 def main():
     args = parse()
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
@@ -791,6 +875,12 @@ def main():
             out["config"]["logged_loss_mean_over_ranks"] = None if loss_mean is None else round(float(loss_mean), 4)
         if verify is not None:
             out["verify_equal_batch"] = verify
+        if world == 1 and args.data == "pipeline":
+            try:
+                out["config"]["data_path"] = data_path_leg(wl, args, dev, tr)
+                out["config"]["data_path"]["resident_input_images_per_s"] = out["value"]
+            except Exception as e:  # noqa: BLE001
+                out["config"]["data_path"] = {"error": repr(e)}
         if world == 1 and not args.no_other_workloads and args.workload == "cfg2":
             # driver-visible numbers for BASELINE.json configs[2] / configs[4] (their single-GPU share): short legs AFTER the headline
             # measurement, models built and released one at a time

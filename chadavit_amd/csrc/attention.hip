@@ -1528,6 +1528,11 @@ extern "C" int chadavit_attn_fwd(const chada_bf16* qkv_, chada_bf16* out_, float
   CHADA_ENTRY();
   if (!qkv_ || !out_ || !lse || !cu_seqlens || !work || n_work <= 0 || n_work % 8 != 0 || T <= 0 || H <= 0 || D % H != 0) return 1;
   const int dh = D / H;
+  // head widths 96 / 192: the 32x32x16-MFMA forward (attention_m32.hip).  CHADAVIT_ATTN_FWD_M32=-1 keeps the 16x16x32 kernels below
+  // (same-box A/B); 1 / 2 select its other softmax variants.
+  static const int m32_variant = getenv("CHADAVIT_ATTN_FWD_M32") ? atoi(getenv("CHADAVIT_ATTN_FWD_M32")) : 0;
+  if (m32_variant >= 0 && (dh == 96 || dh == 192))
+    return chadavit_attn_fwd_m32(qkv_, out_, lse, cu_seqlens, work, n_work, T, D, H, m32_variant, stream);
   const bf16_t* qkv = reinterpret_cast<const bf16_t*>(qkv_);
   bf16_t* out = reinterpret_cast<bf16_t*>(out_);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);

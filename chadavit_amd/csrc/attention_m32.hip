@@ -1,0 +1,420 @@
+// Variable-length flash attention forward on v_mfma_f32_32x32x16_bf16 (gfx950), head widths 96 and 192.
+// replaces chada_vit.py:105-111 (nn.MultiheadAttention + key padding mask), forward.
+//
+// What differs from attention.hip's 16x16x32 forward, and why (measurements: profiles/r03a_coissue*.txt, r03b_attention_fwd.md):
+//   * a wave of the 16x16x32 kernel is bound by its own in-order ISSUE, not by the matrix pipe, LDS or HBM: per (32 queries x 64 keys)
+//     wave-tile it issues 48 MFMAs (16 issue cycles each inside one wave), ~215 VALU (4 cycles, v_exp_f32 8), 36 LDS reads and 6
+//     LDS-DMA pieces (~50-60 cycles each while the CU's other waves feed the same 64 B/clk address path): ~1700 issue cycles against
+//     768 cycles of matrix pipe.  32x32x16 does the same FLOPs in HALF the MFMA instructions;
+//   * S^T = K Q^T with 32x32 tiles leaves 16 keys of ONE query per lane, already in the k-slot order of the B operand of
+//     O^T = V^T P^T: no cross-lane traffic between the two GEMMs; row max / sum need one v_permlane32_swap;
+//   * a leaner softmax (LEAN = 2): the row maximum is taken ONCE, from the first key tile, and kept as the exponent reference of the
+//     whole row -- softmax is invariant to the reference, and fp32 (and bf16: same exponent range) hold exp2 of anything within
+//     +-126 of it.  Per (query, key) that removes the max, the rescale test and the running-max bookkeeping; the scores themselves
+//     are the exact fp32 ones (P = exp2(fma(s, scale * log2 e, -m))).  A row whose later scores exceed the first tile's maximum by more
+//     than 64 (44 nats) is detected at the end (row sum not below 2^64, which also catches inf / NaN) and the whole block re-runs
+//     that work item with the textbook online recurrence (LEAN = 0): same result either way.
+//   * LEAN = 1 additionally folds scale * log2 e into the Q fragments and the reference into the MFMA's C operand (no FMA left): same
+//     speed as LEAN = 2 on the hardware (392 vs 393 us at 1024 x 589 tokens) but a second bf16 rounding of Q -- not used.
+//
+// LDS image of a 64-key (dh 96) / 32-key (dh 192) tile, written by LDS-DMA (buffer_load ... lds, 1 KiB per wave-instruction):
+//   K record (kb, ks):  lane l = K[key kb*32 + (l & 31)][d = ks*16 + (l >> 5)*8 .. +7]  -> A operand of S^T, one conflict-free
+//                       ds_read_b128 at lane * 16;
+//   V record (kp, db):  V[keys kp*16 .. +15][d = db*32 .. +31] row-major (64-byte rows)   -> A operand of O^T by two
+//                       ds_read_b64_tr_b16; each 32-lane half reads 256 contiguous bytes (conflict-free).
+//
+// Built and measured, not kept (sources: scratch/r3/attention_m32_all_variants.hip.txt; numbers: profiles/r03b_attention_fwd.md):
+// 64 query rows per wave at one wave per SIMD, and a software-pipelined body (S'(t+1) MFMAs interleaved with the exponentials of
+// tile t, P V MFMAs with those of tile t+1, fragments two steps ahead, K / V in separate rings) at two waves per SIMD.
+#include <cstdlib>
+
+#include "common.h"
+
+using namespace chada;
+
+namespace {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int TILE = 128;  // query rows per work item (the host's work list, chadavit_attn_tile_rows)
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+constexpr float OVERFLOW_GUARD = 18446744073709551616.0f;  // 2^64: see SAFE
+
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 splat16(float v) {
+  f32x16 r;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) r[e] = v;
+  return r;
+}
+__device__ __forceinline__ bf16x8 pack8f(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7) {
+  bf16x8 r;
+  r[0] = (bf16_t)a0; r[1] = (bf16_t)a1; r[2] = (bf16_t)a2; r[3] = (bf16_t)a3;
+  r[4] = (bf16_t)a4; r[5] = (bf16_t)a5; r[6] = (bf16_t)a6; r[7] = (bf16_t)a7;
+  return r;
+}
+// {v[l], v[l ^ 32]} combined
+__device__ __forceinline__ float half_max(float v) {
+  float a, b;
+  swap32(v, a, b);
+  return fmaxf(a, b);
+}
+__device__ __forceinline__ float half_sum(float v) {
+  float a, b;
+  swap32(v, a, b);
+  return a + b;
+}
+
+template <int DH, int CB, int NW>
+struct Cfg {
+  static constexpr int KVT = (DH > 96) ? 32 : 64;   // keys per tile
+  static constexpr int KS = DH / 16;                // 16-wide k-steps of S^T
+  static constexpr int DB = DH / 32;                // 32-wide head-dim blocks of O^T
+  static constexpr int KB = KVT / 32;               // 32-key blocks of S^T
+  static constexpr int KP = KVT / 16;               // 16-key k-steps of O^T
+  static constexpr int NKR = KB * KS, NVR = KP * DB, NR = NKR + NVR;  // 1 KiB records per stage
+  static constexpr int NRW = NR / NW;               // LDS-DMA instructions per wave and tile
+  static constexpr int STAGE = NR * 512;            // bf16 elements
+  static constexpr int QPB = NW * 32 * CB;          // query rows per block
+  static_assert(NR % NW == 0, "records must split evenly over the waves");
+  static_assert(TILE % QPB == 0, "a work item is a whole number of blocks");
+};
+
+struct WorkItem { int b, t, h, part; };
+template <int SPLIT>
+__device__ __forceinline__ WorkItem decode_work(const int* __restrict__ work, int H) {
+  // same convention as attention.hip: block i runs on XCD i % 8, work-list entry j belongs to XCD j % 8
+  const int lin = blockIdx.x, xcd = lin & 7;
+  int rest = lin >> 3;
+  WorkItem it;
+  it.part = rest % SPLIT; rest /= SPLIT;
+  it.h = rest % H;
+  const int wi = (rest / H) * 8 + xcd;
+  it.b = work[2 * wi];
+  it.t = work[2 * wi + 1];
+  return it;
+}
+
+// One key tile.  MODE 0: textbook online softmax (running max m, rescale);  MODE 1: the first tile of the diet path (takes the
+// row maximum, which becomes the fixed reference held in `minit` = -m);  MODE 2: diet steady state (no max, no FMA, no rescale).
+// In MODE 1 / 2 the Q fragments carry the scale (c == 1 is passed).
+template <int DH, int CB, int NW, int MODE, bool MASKED>
+__device__ __forceinline__ void fwd_tile(BufRsrc qb, bf16_t* __restrict__ dst, const bf16_t* __restrict__ sK, bool issue, int kt, int len,
+                                         int qrow0, unsigned ldu, float c, int w, int l, const int (&rec_row)[Cfg<DH, CB, NW>::NRW],
+                                         const unsigned (&rec_col)[Cfg<DH, CB, NW>::NRW], const bf16x8 (&qf)[CB][Cfg<DH, CB, NW>::KS],
+                                         f32x16 (&o)[CB][Cfg<DH, CB, NW>::DB], float (&m)[CB], float (&ls)[CB], f32x16 (&minit)[CB]) {
+  using C = Cfg<DH, CB, NW>;
+  constexpr int KS = C::KS, DB = C::DB, KB = C::KB, KP = C::KP, KVT = C::KVT, NKR = C::NKR, NRW = C::NRW;
+  const int hi = l >> 5;
+  if (issue) {
+#pragma unroll
+    for (int i = 0; i < NRW; ++i) {
+      const unsigned off = (unsigned)min((kt + 1) * KVT + rec_row[i], len - 1) * ldu + rec_col[i];
+      lds_dma16(qb, dst + (w + NW * i) * 512, off * 2, 0);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);  // the DMA goes out first (see attention.hip / DESIGN 3a)
+  if (qrow0 >= len) return;           // (wave-uniform) no query row of this wave exists: it only feeds the DMA and the barriers
+  const bf16_t* sV = sK + NKR * 512;
+  const int valid = MASKED ? (len - kt * KVT) : KVT;       // valid keys in this tile (>= 1)
+  const int nkb = MASKED ? min(KB, (valid + 31) >> 5) : KB;
+  const int nkp = MASKED ? min(KP, (valid + 15) >> 4) : KP;
+
+  // ---- S^T = K Q^T (+ the C operand: zero, or -m in the diet steady state).  (Requesting the fragments two steps ahead through a
+  // register ring, as attention.hip does, costs this kernel its third wave per SIMD at dh = 96 -- 168 registers -- and measured
+  // slower: 472 against ~380 us; hipcc's own placement stays.)
+  f32x16 s[CB][KB];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+    if (MASKED && kb >= nkb) continue;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const bf16x8 kf = lds_read8(sK + (kb * KS + ks) * 512 + l * 8);
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+        if (ks == 0)
+          s[cb][kb] = mfma32(kf, qf[cb][0], MODE == 2 ? minit[cb] : splat16(0.f));
+        else
+          s[cb][kb] = mfma32(kf, qf[cb][ks], s[cb][kb]);
+      }
+    }
+  }
+  // ---- softmax
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb) {
+    if (MASKED) {
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        if (kb >= nkb) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kb * 32 + 8 * (r >> 2) + 4 * hi + (r & 3) >= valid) s[cb][kb][r] = -INFINITY;
+      }
+    }
+    float ps = 0.f;
+    if (MODE == 4) {  // fixed reference m (taken from the first tile), exact scores: one FMA + exp per score, no maximum
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        if (MASKED && kb >= nkb) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p = __builtin_amdgcn_exp2f(fmaf(s[cb][kb][r], c, -m[cb]));
+          s[cb][kb][r] = p;
+          ps += p;
+        }
+      }
+      ls[cb] += ps;
+    } else if (MODE == 2) {
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        if (MASKED && kb >= nkb) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p = __builtin_amdgcn_exp2f(s[cb][kb][r]);
+          s[cb][kb][r] = p;
+          ps += p;
+        }
+      }
+      ls[cb] += ps;
+    } else {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        if (MASKED && kb >= nkb) continue;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, s[cb][kb][r]), s[cb][kb][r + 1]);
+      }
+      mx = half_max(mx);
+      const float mn = fmaxf(m[cb], mx * c);
+      const float alpha = __builtin_amdgcn_exp2f(m[cb] - mn);
+      m[cb] = mn;
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        if (MASKED && kb >= nkb) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p = __builtin_amdgcn_exp2f(fmaf(s[cb][kb][r], c, -mn));
+          s[cb][kb][r] = p;
+          ps += p;
+        }
+      }
+      ls[cb] = ls[cb] * alpha + ps;
+      if (MODE == 0) {
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+#pragma unroll
+          for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[cb][db][r] *= alpha;
+        }
+      } else {
+        minit[cb] = splat16(-mn);  // (first tile: o and ls are still zero, nothing to rescale)
+      }
+    }
+  }
+  // ---- O^T += V^T P^T: P of k-step kp = registers 8 (kp & 1) .. +7 of the 32-key block kp >> 1, already in B-operand order
+#pragma unroll
+  for (int kp = 0; kp < KP; ++kp) {
+    if (MASKED && kp >= nkp) continue;
+    bf16x8 pf[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+      const f32x16& sv = s[cb][kp >> 1];
+      const int b0 = 8 * (kp & 1);
+      pf[cb] = pack8f(sv[b0], sv[b0 + 1], sv[b0 + 2], sv[b0 + 3], sv[b0 + 4], sv[b0 + 5], sv[b0 + 6], sv[b0 + 7]);
+    }
+    const int g = l >> 4, ii = l & 15;
+    const bf16_t* vrow = sV + kp * DB * 512 + (4 * (g >> 1) + (ii >> 2)) * 32 + (g & 1) * 16 + (ii & 3) * 4;
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+      const bf16x4 lo = lds_read_tr4(vrow + db * 512);
+      const bf16x4 hi4 = lds_read_tr4(vrow + db * 512 + 8 * 32);
+      const bf16x8 vf = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) o[cb][db] = mfma32(vf, pf[cb], o[cb][db]);
+    }
+  }
+}
+
+// All key tiles of one work item for this block.  Returns with o / m / ls final.
+template <int DH, int CB, int NW, int LEAN>
+__device__ __forceinline__ void fwd_item(BufRsrc qrs, bf16_t* smem, int len, int qrow0, unsigned ldu, float c, int w, int l,
+                                         const int (&rec_row)[Cfg<DH, CB, NW>::NRW], const unsigned (&rec_col)[Cfg<DH, CB, NW>::NRW],
+                                         const bf16x8 (&qf)[CB][Cfg<DH, CB, NW>::KS], f32x16 (&o)[CB][Cfg<DH, CB, NW>::DB], float (&m)[CB],
+                                         float (&ls)[CB]) {
+  using C = Cfg<DH, CB, NW>;
+  constexpr int KVT = C::KVT, NRW = C::NRW, STAGE = C::STAGE, DB = C::DB;
+  f32x16 minit[CB];
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb) {
+    m[cb] = -INFINITY;
+    ls[cb] = 0.f;
+    minit[cb] = splat16(0.f);
+#pragma unroll
+    for (int db = 0; db < DB; ++db) o[cb][db] = splat16(0.f);
+  }
+  const int nkt = (len + KVT - 1) / KVT;
+  // tile 0: no LDS read follows before the first barrier, issued bare
+#pragma unroll
+  for (int i = 0; i < NRW; ++i) {
+    const unsigned off = (unsigned)min(rec_row[i], len - 1) * ldu + rec_col[i];
+    lds_dma16(qrs, smem + (w + NW * i) * 512, off * 2, 0);
+  }
+  constexpr int M_FIRST = LEAN ? 1 : 0, M_REST = LEAN == 1 ? 2 : (LEAN == 2 ? 4 : 0);
+  if (nkt == 1) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    fwd_tile<DH, CB, NW, M_FIRST, true>(qrs, smem + STAGE, smem, false, 0, len, qrow0, ldu, c, w, l, rec_row, rec_col, qf, o, m, ls, minit);
+    return;
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  fwd_tile<DH, CB, NW, M_FIRST, false>(qrs, smem + STAGE, smem, true, 0, len, qrow0, ldu, c, w, l, rec_row, rec_col, qf, o, m, ls, minit);
+  for (int kt = 1; kt < nkt - 1; ++kt) {
+    // tile kt has landed (LDS-DMA completion is visible only through the issuing wave's vmcnt) and everybody is done reading
+    // the other stage
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    fwd_tile<DH, CB, NW, M_REST, false>(qrs, smem + ((kt + 1) & 1) * STAGE, smem + (kt & 1) * STAGE, true, kt, len, qrow0, ldu, c, w, l, rec_row,
+                                        rec_col, qf, o, m, ls, minit);
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  fwd_tile<DH, CB, NW, M_REST, true>(qrs, smem + (nkt & 1) * STAGE, smem + ((nkt - 1) & 1) * STAGE, false, nkt - 1, len, qrow0, ldu, c, w, l,
+                                     rec_row, rec_col, qf, o, m, ls, minit);
+}
+
+template <int DH, int CB, int NW, int LEAN>
+__global__ __launch_bounds__(64 * NW, (CB > 1 ? 1 : (DH <= 96 ? 3 : 2))) void attn_fwd_m32_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                                                    float* __restrict__ lse, const int* __restrict__ cu,
+                                                                                    const int* __restrict__ work, int T, int D, int H,
+                                                                                    float scale) {
+  using C = Cfg<DH, CB, NW>;
+  constexpr int KS = C::KS, DB = C::DB, NKR = C::NKR, NRW = C::NRW, STAGE = C::STAGE, QPB = C::QPB;
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * STAGE];
+
+  const int tid = threadIdx.x, l = tid & 63, hi = l >> 5, li = l & 31;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int SPLIT = TILE / QPB;
+  const WorkItem it = decode_work<SPLIT>(work, H);
+  const int b = it.b, qt = it.t, h = it.h, part = it.part;
+  if (b < 0) return;
+  const int seq0 = cu[b], len = cu[b + 1] - seq0;
+  if (qt * TILE + part * QPB >= len) return;
+  const size_t ld = 3 * (size_t)D;
+  const bf16_t* qbase = qkv + (size_t)seq0 * ld + h * DH;
+  const float c = scale * LOG2E;
+
+  // Q as the B operand of S^T: lane l = Q[row q0 + (l & 31)][d = ks*16 + (l >> 5)*8 .. +7]; LEAN: times scale*log2(e), rounded once
+  bf16x8 qf[CB][KS];
+  int qrow[CB];
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb) {
+    qrow[cb] = qt * TILE + part * QPB + w * 32 * CB + cb * 32 + li;
+    const int qr = min(qrow[cb], len - 1);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      bf16x8 v = *reinterpret_cast<const bf16x8*>(qbase + (size_t)qr * ld + ks * 16 + hi * 8);
+      if (LEAN == 1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] * c);
+      }
+      qf[cb][ks] = v;
+    }
+  }
+  // record r of a tile is fetched by wave r % NW (instruction r / NW of that wave)
+  int rec_row[NRW];
+  unsigned rec_col[NRW];
+#pragma unroll
+  for (int i = 0; i < NRW; ++i) {
+    const int r = w + NW * i;
+    if (r < NKR) {
+      rec_row[i] = (r / KS) * 32 + li;
+      rec_col[i] = D + (r % KS) * 16 + hi * 8;
+    } else {
+      const int rv = r - NKR;
+      rec_row[i] = (rv / DB) * 16 + (l >> 2);
+      rec_col[i] = 2 * D + (rv % DB) * 32 + (l & 3) * 8;
+    }
+  }
+  const unsigned ldu = 3u * (unsigned)D;
+  const int qrow0 = qt * TILE + part * QPB + w * 32 * CB;  // first query row of this wave
+  const BufRsrc qrs = make_rsrc(qbase);
+
+  f32x16 o[CB][DB];
+  float m[CB], ls[CB], lt[CB];
+  fwd_item<DH, CB, NW, LEAN>(qrs, smem, len, qrow0, ldu, LEAN == 1 ? 1.0f : c, w, l, rec_row, rec_col, qf, o, m, ls);
+  bool bad = false;
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb) {
+    lt[cb] = half_sum(ls[cb]);
+    if (LEAN && qrow0 < len) bad |= !(lt[cb] < OVERFLOW_GUARD);
+  }
+  if (LEAN) {
+    // Fixed-reference softmax went out of range for some row (a score more than 64 above the first tile's maximum, or inf / NaN
+    // inputs): the BLOCK re-runs the item with the running-max recurrence (block-uniform: the tile loop has barriers).  The
+    // per-wave flags live in the stage the last tile did not read (no second __shared__ object: DESIGN 3a).
+    const int nkt = (len + C::KVT - 1) / C::KVT;
+    int* flags = reinterpret_cast<int*>(smem + (nkt & 1) * STAGE);
+    const bool wbad = __builtin_amdgcn_ballot_w64(bad) != 0;
+    if (l == 0) flags[w] = wbad ? 1 : 0;
+    __syncthreads();
+    int any = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) any |= flags[i];
+    if (any) {
+      __syncthreads();  // everybody has read the flags before the re-run's first DMA may land on them
+      fwd_item<DH, CB, NW, 0>(qrs, smem, len, qrow0, ldu, LEAN == 1 ? 1.0f : c, w, l, rec_row, rec_col, qf, o, m, ls);
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) lt[cb] = half_sum(ls[cb]);
+    }
+  }
+  if (qrow0 >= len) return;
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb) {
+    const float inv = 1.0f / lt[cb];
+    if (qrow[cb] < len) {
+      // accumulator register r of block db = O[query][d = db*32 + 8 (r >> 2) + 4 hi + (r & 3)]: four consecutive d per quad
+      bf16_t* orow = out + (size_t)(seq0 + qrow[cb]) * D + h * DH + 4 * hi;
+#pragma unroll
+      for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4)
+          *reinterpret_cast<bf16x4*>(orow + db * 32 + 8 * q4) =
+              pack4(o[cb][db][4 * q4] * inv, o[cb][db][4 * q4 + 1] * inv, o[cb][db][4 * q4 + 2] * inv, o[cb][db][4 * q4 + 3] * inv);
+      if (hi == 0) lse[(size_t)h * T + seq0 + qrow[cb]] = (m[cb] + log2f(lt[cb])) * LN2;
+    }
+  }
+}
+
+
+}  // namespace
+
+// variant: 0 / 5 = lean softmax on exact scores (what chadavit_attn_fwd dispatches to), 1 = textbook online softmax, 2 = lean softmax with
+// the scale folded into Q (see the file header)
+extern "C" int chadavit_attn_fwd_m32(const chada_bf16* qkv_, chada_bf16* out_, float* lse, const int* cu_seqlens, const int* work,
+                                     int n_work, int T, int D, int H, int variant, void* stream) {
+  CHADA_ENTRY();
+  if (!qkv_ || !out_ || !lse || !cu_seqlens || !work || n_work <= 0 || n_work % 8 != 0 || T <= 0 || H <= 0 || D % H != 0) return 1;
+  const int dh = D / H;
+  const bf16_t* qkv = reinterpret_cast<const bf16_t*>(qkv_);
+  bf16_t* out = reinterpret_cast<bf16_t*>(out_);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const float scale = 1.0f / sqrtf((float)dh);
+#define M32_LAUNCH(DHV, CBV, NWV, LEANV)                                                                                              \
+  hipLaunchKernelGGL((attn_fwd_m32_kernel<DHV, CBV, NWV, LEANV>), dim3(n_work * (TILE / (NWV * 32 * CBV)) * H), dim3(64 * NWV), 0, s, qkv, out, \
+                     lse, cu_seqlens, work, T, D, H, scale)
+  const int lean = variant == 1 ? 0 : (variant == 2 ? 1 : 2);
+  if (dh == 96) {
+    if (lean == 0) M32_LAUNCH(96, 1, 4, 0);
+    else if (lean == 1) M32_LAUNCH(96, 1, 4, 1);
+    else M32_LAUNCH(96, 1, 4, 2);
+  } else if (dh == 192) {
+    if (lean == 0) M32_LAUNCH(192, 1, 4, 0);
+    else if (lean == 1) M32_LAUNCH(192, 1, 4, 1);
+    else M32_LAUNCH(192, 1, 4, 2);
+  } else {
+    return 2;
+  }
+#undef M32_LAUNCH
+  CHADA_CHECK_LAUNCH();
+  return 0;
+}

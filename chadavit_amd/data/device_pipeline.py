@@ -127,6 +127,11 @@ class DeviceMultiCropPipeline:
         self.rng = random.Random(seed)            # stands for Python's global `random` (albumentations' source of randomness)
         self.np_rng = np.random.RandomState(seed)  # stands for numpy's global RNG (CustomColorJitter draws from it)
         self.last_params: List[CropParams] = []
+        # pinned staging for the raw planes: a ring of three buffers, each guarded by the event of the copy that last read it (a
+        # fresh pin_memory() per batch costs more than the copy it feeds)
+        self._staging: List[Optional[torch.Tensor]] = [None, None, None]
+        self._staging_ev: List[Optional["torch.cuda.Event"]] = [None, None, None]
+        self._calls = 0
 
     @property
     def num_crops(self) -> int:
@@ -179,10 +184,23 @@ class DeviceMultiCropPipeline:
         for (C, H, W) in shapes:
             offs.append(tot)
             tot += C * H * W
-        host = torch.empty(tot, dtype=torch.float32).pin_memory() if self.device.type == "cuda" else torch.empty(tot, dtype=torch.float32)
+        if self.device.type == "cuda":
+            k = self._calls % 3
+            self._calls += 1
+            if self._staging_ev[k] is not None:
+                self._staging_ev[k].synchronize()   # (three batches ago: long complete)
+            if self._staging[k] is None or self._staging[k].numel() < tot:
+                self._staging[k] = torch.empty(max(tot, 1), dtype=torch.float32).pin_memory()
+            host = self._staging[k][:tot]
+        else:
+            host = torch.empty(tot, dtype=torch.float32)
+        hn = host.numpy()
         for o, im in zip(offs, planes):
-            host[o:o + im.size] = torch.from_numpy(im.reshape(-1))
+            hn[o:o + im.size] = im.reshape(-1)
         src = host.to(self.device, non_blocking=True)
+        if self.device.type == "cuda":
+            self._staging_ev[k] = torch.cuda.Event()
+            self._staging_ev[k].record(torch.cuda.current_stream(self.device))
         crops, used = [], []
         it = iter(params) if params is not None else None
         nchan = sum(nch)

@@ -1,0 +1,108 @@
+"""Prefetching front end of the device data path: reader threads -> pinned staging -> H2D copy + augmentation
+kernels on a SIDE HIP stream, `depth` batches ahead of the training step.
+
+The reference feeds its step from `DataLoader(dataset, collate_fn=one_channel_collate_fn, num_workers=...)`
+(pretrain_dataloader.py:517-525): worker processes decode the channel files and run the albumentations chain on the CPU.
+Here the workers only DECODE (`dataset.read_planes`, PIL releases the GIL); everything after that -- the copy of the raw planes and
+the crop / jitter / blur kernels of `DeviceMultiCropPipeline` -- runs on the GPU, on a stream of its own, while the previous step
+computes.  The consumer orders itself behind a batch with one event wait; nothing blocks the host.
+
+    ds = IDRCell100K(root_dir=..., train=True)
+    sampler = TokenBalancedBatchSampler(ds.num_channels(), global_batch, rank, world)
+    loader = DevicePrefetcher(ds, sampler, DeviceMultiCropPipeline(specs, device, seed=rank), workers=16)
+    for step, batch in enumerate(loader):        # batch = (crops, labels, list_num_channels), as one_channel_collate_fn returns
+        trainer.train_step(batch, step)
+"""
+from __future__ import annotations
+
+import queue
+import threading
+from concurrent.futures import ThreadPoolExecutor
+from typing import Iterable, Iterator, List, Optional, Sequence
+
+import torch
+
+
+class DevicePrefetcher:
+    def __init__(self, dataset, batch_sampler: Iterable[Sequence[int]], pipeline, depth: int = 2, workers: int = 8,
+                 labels: Optional[Sequence[int]] = None):
+        self.dataset, self.batch_sampler, self.pipeline = dataset, batch_sampler, pipeline
+        self.depth, self.workers, self.labels = max(1, depth), max(1, workers), labels
+        self.device = pipeline.device
+        self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        self.read_s = 0.0      # host seconds spent decoding (sum over batches; the reader threads' wall time per batch)
+        self.batches = 0
+
+    def __len__(self):
+        return len(self.batch_sampler)
+
+    def _produce(self, q: "queue.Queue", stop: threading.Event):
+        import time
+        try:
+            if self.stream is not None:
+                torch.cuda.set_device(self.device)
+            with ThreadPoolExecutor(max_workers=self.workers) as pool:
+                for idx in self.batch_sampler:
+                    if stop.is_set():
+                        break
+                    t0 = time.perf_counter()
+                    planes = list(pool.map(self.dataset.read_planes, idx))
+                    self.read_s += time.perf_counter() - t0
+                    labs = [self.labels[i] for i in idx] if self.labels is not None else None
+                    if self.stream is not None:
+                        with torch.cuda.stream(self.stream):
+                            batch = self.pipeline(planes, labels=labs)
+                            ev = torch.cuda.Event()
+                            ev.record(self.stream)
+                    else:
+                        batch, ev = self.pipeline(planes, labels=labs), None
+                    self.batches += 1
+                    q.put((batch, ev))
+            q.put(None)
+        except BaseException as e:  # noqa: BLE001 - handed to the consumer
+            q.put(e)
+
+    def __iter__(self) -> Iterator:
+        q: "queue.Queue" = queue.Queue(maxsize=self.depth)
+        stop = threading.Event()
+        th = threading.Thread(target=self._produce, args=(q, stop), daemon=True)
+        th.start()
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                batch, ev = item
+                if ev is not None:
+                    cur = torch.cuda.current_stream(self.device)
+                    cur.wait_event(ev)
+                    crops = batch[0] if isinstance(batch[0], (list, tuple)) else [batch[0]]
+                    for c in crops:   # allocated on the side stream, consumed on this one
+                        c.record_stream(cur)
+                    batch[1].record_stream(cur)
+                yield batch
+        finally:
+            stop.set()
+            while th.is_alive():   # unblock a producer waiting on a full queue
+                try:
+                    q.get_nowait()
+                except queue.Empty:
+                    th.join(timeout=0.05)
+
+
+class InMemoryPlanes:
+    """A dataset of raw planes held in host memory (synthetic or pre-decoded): the reader side of the path without the disk."""
+
+    def __init__(self, planes: List):
+        self.planes = planes
+
+    def __len__(self):
+        return len(self.planes)
+
+    def num_channels(self) -> List[int]:
+        return [int(p.shape[0]) for p in self.planes]
+
+    def read_planes(self, index: int):
+        return self.planes[index]

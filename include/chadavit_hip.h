@@ -128,6 +128,13 @@ int chadavit_layernorm_bwd_pair(const chada_bf16* dy, const chada_bf16* x, const
  * --------------------------------------------------------------------------------------------- */
 int chadavit_attn_fwd(const chada_bf16* qkv, chada_bf16* out, float* lse, const int* cu_seqlens, const int* work,
                       int n_work, int T, int D, int H, void* stream);
+/* The same operation on v_mfma_f32_32x32x16_bf16 tiles for head widths 96 / 192 (csrc/attention_m32.hip): half the MFMA
+ * instructions per FLOP and a leaner softmax -- the row maximum is taken once per row, from the first key tile, and kept as the
+ * exponent reference; rows that leave its range re-run with the online recurrence (same result).  variant: 0 = that (default),
+ * 1 = textbook online softmax, 2 = lean softmax with the scale folded into Q.  chadavit_attn_fwd dispatches here for dh 96 / 192.
+ * replaces chada_vit.py:105-111 forward. */
+int chadavit_attn_fwd_m32(const chada_bf16* qkv, chada_bf16* out, float* lse, const int* cu_seqlens, const int* work, int n_work, int T,
+                          int D, int H, int variant, void* stream);
 
 /* Attention of ONE query row per sequence -- the CLS row (first row of each sequence) -- against all keys of its sequence.
  * With return_all_tokens = False (args/pretrain.py:147) only norm(x)[:, 0] leaves ChAdaViT.forward (chada_vit.py:272-289): of the

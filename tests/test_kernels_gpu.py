@@ -230,12 +230,17 @@ def test_layernorm_bwd_pair_equals_two_calls(T, D, acc):
     got = [torch.full((D,), init, device=dev) for _ in range(4)]
     dz = ops.layernorm_bwd_pair(dy, x, st[0], st[1], ga, dres, z, st[2], st[3], gb, got[0], got[1], got[2], got[3], ws,
                                 accumulate_a=acc, accumulate_b=acc)
-    # the instance that rebuilds x from z instead of reading it: x = bf16(LN_b(z)) is reproduced bit for bit, so is everything else
+    # the instance that rebuilds x from z instead of reading it: x = bf16(LN_b(z)) is reproduced bit for bit (ln_apply, explicit FMA);
+    # the two template instances are separate compilations whose implicit multiply-add contractions may differ (they did once packed
+    # f32 ops were switched off, round 3), so dz agrees to one bf16 ulp and the column sums to fp32 rounding, as for the two-call path
     got2 = [torch.full((D,), init, device=dev) for _ in range(4)]
     dz2 = ops.layernorm_bwd_pair(dy, x, st[0], st[1], ga, dres, z, st[2], st[3], gb, got2[0], got2[1], got2[2], got2[3], ws,
                                  accumulate_a=acc, accumulate_b=acc, beta_b=bb)
     torch.cuda.synchronize()
-    assert torch.equal(dz2, dz) and all(torch.equal(a, b) for a, b in zip(got2, got))
+    e2 = (dz2.float() - dz.float()).abs()
+    assert bool((e2 <= 2 ** -7 * dz.float().abs() + 2e-3 * float(dz.float().abs().max())).all()) and float((e2 > 0).float().mean()) < 0.01, float(e2.max())
+    for a, b in zip(got2, got):
+        assert float((a - b).abs().max()) <= 1e-5 * max(float(b.abs().max()), 1.0), float((a - b).abs().max())
     err = (dz.float() - dz_ref.float()).abs()
     # one bf16 ulp of the element, or of the intermediate dx spread over its row (small |dz| next to large ones)
     assert bool((err <= 2 ** -7 * dz_ref.float().abs() + 2e-3 * float(dz_ref.float().abs().max())).all()), float(err.max())
@@ -348,6 +353,59 @@ def test_attention_lengths_around_the_tile_boundaries(D):
     # nothing leaks between neighbouring sequences or beyond the last row
     out2, _ = ops.attn_fwd(qkv, rb.cu_seqlens, rb.work, H)
     assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("D", [192, 384])
+def test_attention_fwd_m32_variants_and_out_of_range_rerun(D):
+    """csrc/attention_m32.hip (the forward chadavit_attn_fwd dispatches to at dh = 96 / 192): the lean softmax keeps the FIRST key
+    tile's row maximum as the exponent reference of the whole row.  (a) its three variants against fp32 torch, LSE included;
+    (b) a row whose later scores exceed that reference by more than 2^64 -- a query / key pair with a raw score of ~600 placed in
+    a later tile, and in the LAST (masked) tile -- must take the block-wide re-run with the online recurrence and still match;
+    (c) the default dispatch IS that kernel (bit-identical to variant 0), and the 16x16x32 kernels agree with it."""
+    import ctypes
+    from chadavit_amd import ops
+    from chadavit_amd._lib import lib
+    from chadavit_amd.ragged import RaggedBatch
+    dev = _dev()
+    H = 2
+    dh = D // H
+
+    def fwd(qkv, rb, variant):
+        out = torch.empty((rb.T, D), device=dev, dtype=torch.bfloat16)
+        lse = torch.empty((H, rb.T), device=dev, dtype=torch.float32)
+        rc = lib().chadavit_attn_fwd_m32(ctypes.c_void_p(qkv.data_ptr()), ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(lse.data_ptr()),
+                                         ctypes.c_void_p(rb.cu_seqlens.data_ptr()), ctypes.c_void_p(rb.work.data_ptr()),
+                                         ctypes.c_int(rb.n_work), ctypes.c_int(rb.T), ctypes.c_int(D), ctypes.c_int(H), ctypes.c_int(variant),
+                                         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0
+        return out, lse
+
+    def ref_lse(qkv, cu):
+        q, k, _ = qkv.float().split(D, dim=1)
+        out = torch.empty((H, qkv.shape[0]), device=dev)
+        for i in range(len(cu) - 1):
+            a, b = cu[i], cu[i + 1]
+            for h in range(H):
+                out[h, a:b] = torch.logsumexp(q[a:b, h * dh:(h + 1) * dh] @ k[a:b, h * dh:(h + 1) * dh].T / math.sqrt(dh), dim=1)
+        return out
+
+    rb = RaggedBatch([3, 1, 3], 196, dev)   # 589, 197, 589 tokens
+    for spike in (None, (300, 500), (10, 588), (786 + 5, 786 + 588)):   # (query row, key row): later tile / last masked tile / third image
+        qkv = _rand((rb.T, 3 * D), 12, 1.0).bfloat16().to(dev)
+        if spike is not None:
+            qkv[spike[0], :dh] = 2.5
+            qkv[spike[1], D:D + dh] = 2.5     # raw score 6.25 dh = 600 (dh 96) / 1200 (dh 192): far beyond tile 0's maximum + 2^64
+        ref = _attn_ref(qkv.float(), rb.host_cu_seqlens, H)
+        lref = ref_lse(qkv, rb.host_cu_seqlens)
+        for variant in (0, 1, 2):
+            out, lse = fwd(qkv, rb, variant)
+            _close(out, ref, 2e-2, 2e-2, f"attn_fwd_m32 variant {variant} spike {spike}")
+            assert torch.isfinite(lse).all()
+            if variant != 2:   # (variant 2 rounds the scaled Q a second time: its LSE carries that rounding, |score| * 2^-9)
+                assert float((lse - lref).abs().max()) < 2e-3, (variant, spike, float((lse - lref).abs().max()))
+        out_d, lse_d = ops.attn_fwd(qkv, rb.cu_seqlens, rb.work, H)
+        out_0, lse_0 = fwd(qkv, rb, 0)
+        assert torch.equal(out_d, out_0) and torch.equal(lse_d, lse_0)
 
 
 def test_tokenizer_path():
