@@ -610,7 +610,7 @@ def launch_profile(tr, batch, step0, nch, wl, dev, rank, in_step_steps=2):
     return summ
 
 
-def other_workload_leg(name, args, dev, steps=3, warmup=2):
+def other_workload_leg(name, args, dev, steps=3, warmup=2, graph=False):
     """A short leg of another BASELINE.json config on the same box, after the headline measurement (N = 1): images/s over
     `steps` steps, the dominant entry point and its roofline fraction -- so that the driver's own bench record carries numbers
     for configs[2] / configs[4] too.  Same step, same code path as a `--workload NAME` run."""
@@ -618,22 +618,29 @@ def other_workload_leg(name, args, dev, steps=3, warmup=2):
     import torch
     wl = dict(WORKLOADS[name])
     model, tr, _, batch, nch, _ = build_workload(wl, args, 0, 1, dev)
+    step_fn = tr.train_step
+    if graph:   # the launch-bound regime: the whole step replayed as one hipGraph (chadavit_amd.graphed)
+        from chadavit_amd.graphed import GraphedTrainStep
+        step_fn = GraphedTrainStep(tr)
     for i in range(warmup):
-        tr.train_step(batch, i)
+        step_fn(batch, i)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
-        last = tr.train_step(batch, warmup + i)
+        last = step_fn(batch, warmup + i)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if graph:
+        step_fn.close()
     res = {"workload": wl["desc"], "images_per_gpu": wl["batch"], "images_per_s": round(wl["batch"] * steps / dt, 2),
            "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps, "warmup": warmup, "final_loss": round(float(last.item()), 4),
-           "dtype": "fp8-weights (MX e4m3 x e4m3 forward GEMMs; bf16 elsewhere)" if wl.get("weight_dtype") == "fp8" else "bf16"}
+           "dtype": "fp8-weights (MX e4m3 x e4m3 forward GEMMs; bf16 elsewhere)" if wl.get("weight_dtype") == "fp8" else "bf16",
+           "launch": "one hipGraph per step (GraphedTrainStep)" if graph else "eager"}
     chans = list(range(1, 11)) if "-" in wl["channels"] else [int(wl["channels"])]
     gf_exec = gflop_per_image(chans, wl["D"], wl["P"], wl["n_global"], wl["n_local"], cls_last=bool(model.backbone.cls_only_last_block))
     res["executed_gflop_per_image"] = round(gf_exec, 1)
     res["mfma_fraction_whole_step"] = round(res["images_per_s"] * gf_exec / 1e3 / PEAK_BF16_TFLOPS, 4)
-    if not args.no_launch_profile:
+    if not args.no_launch_profile and not graph:
         summ = launch_profile(tr, batch, warmup + steps, nch, wl, dev, 0, in_step_steps=1)
         roof, _ = roofline_object(summ, model, nch, wl)
         res.update({"dominant_kernel": roof["kernel"], "dominant_avg_us": roof["avg_us"], "bound": roof["bound"], "frac": roof["frac"],
@@ -890,9 +897,9 @@ def main():
             gc.collect()
             torch.cuda.empty_cache()
             legs = {}
-            for name in ("cfg3", "cfg5"):
+            for name, kw in (("cfg3", {}), ("cfg5", {}), ("cfg1", {"steps": 30, "warmup": 3}), ("cfg1-graph", {"steps": 30, "warmup": 3, "graph": True})):
                 try:
-                    legs[name] = other_workload_leg(name, args, dev)
+                    legs[name] = other_workload_leg(name.split("-")[0], args, dev, **kw)
                 except Exception as e:  # noqa: BLE001 - the headline number must still be reported
                     legs[name] = {"error": repr(e)}
             out["config"]["other_workloads"] = legs

@@ -99,8 +99,9 @@ __global__ __launch_bounds__(256) void weightnorm_bwd_kernel(const float* __rest
 __global__ __launch_bounds__(256) void dino_loss_kernel(const float* __restrict__ student, const float* __restrict__ teacher,
                                                         const float* __restrict__ center, float inv_ts, float inv_tt,
                                                         float* __restrict__ loss_rows, bf16_t* __restrict__ dstudent, int B,
-                                                        int P) {
+                                                        int P, const float* __restrict__ teacher_temp_dev) {
   __shared__ float red[4];
+  if (teacher_temp_dev) inv_tt = 1.0f / teacher_temp_dev[0];  // device-resident step scalar (graph-captured training step)
   const int b = blockIdx.x, tid = threadIdx.x;
   const float* s0 = student + (size_t)b * P;
   const float* s1 = student + (size_t)(B + b) * P;
@@ -187,7 +188,9 @@ __global__ __launch_bounds__(256) void center_ema_kernel(float* __restrict__ cen
 }
 
 // ---- flat parameter kernels ----------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ t, const float* __restrict__ s, float tau, size_t n) {
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ t, const float* __restrict__ s, float tau, size_t n,
+                                                  const float* __restrict__ tau_dev) {
+  if (tau_dev) tau = tau_dev[0];
   const size_t n4 = n / 4;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     const f32x4 a = reinterpret_cast<const f32x4*>(t)[i], b = reinterpret_cast<const f32x4*>(s)[i];
@@ -201,7 +204,8 @@ __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ t, const f
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, float lr, float b1, float b2, float eps, float wd,
-                                                    float bc1, float bc2_sqrt, size_t n) {
+                                                    float bc1, float bc2_sqrt, size_t n, const float* __restrict__ hyper) {
+  if (hyper) { lr = hyper[0]; bc1 = hyper[1]; bc2_sqrt = hyper[2]; }  // {lr, 1 - beta1^t, sqrt(1 - beta2^t)} of this step, on the device
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const float gg = g[i];
     float pp = p[i] * (1.0f - lr * wd);
@@ -429,7 +433,7 @@ __global__ __launch_bounds__(256) void knn_vote_kernel(const float* __restrict__
 
 }  // namespace
 
-extern "C" int chadavit_abi_version(void) { return 3; }
+extern "C" int chadavit_abi_version(void) { return 4; }
 
 extern "C" int chadavit_l2norm_fwd(const float* x, chada_bf16* y, float* inv_norm, int M, int N, void* stream) {
   CHADA_ENTRY();
@@ -474,7 +478,7 @@ extern "C" int chadavit_dino_loss(const float* student, const float* teacher, co
   if (!student || !teacher || !center || !loss_rows || B <= 0 || P <= 0 || student_temp <= 0.f || teacher_temp <= 0.f) return 1;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(dino_loss_kernel, dim3(B), dim3(256), 0, s, student, teacher, center, 1.0f / student_temp,
-                     1.0f / teacher_temp, loss_rows, reinterpret_cast<bf16_t*>(dstudent), B, P);
+                     1.0f / teacher_temp, loss_rows, reinterpret_cast<bf16_t*>(dstudent), B, P, (const float*)nullptr);
   if (teacher_colsum)
     hipLaunchKernelGGL(sum_rows_kernel, dim3((P + 63) / 64), dim3(256), 0, s, teacher, teacher_colsum, 2 * B, P, 1.0f,
                        (int)((P & 3) == 0 && ((uintptr_t)teacher & 15) == 0));
@@ -503,7 +507,7 @@ extern "C" int chadavit_ema_update(float* teacher, const float* student, float t
   if (!teacher || !student || n <= 0) return 1;
   if (((uintptr_t)teacher | (uintptr_t)student) & 15) return 2;
   hipLaunchKernelGGL(ema_kernel, dim3(grid_for((size_t)n / 4 + 1, 2048)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     teacher, student, tau, (size_t)n);
+                     teacher, student, tau, (size_t)n, (const float*)nullptr);
   CHADA_CHECK_LAUNCH();
   return 0;
 }
@@ -513,7 +517,44 @@ extern "C" int chadavit_adamw_step(float* param, const float* grad, float* exp_a
   CHADA_ENTRY();
   if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || bias_corr1 <= 0.f || bias_corr2 <= 0.f) return 1;
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((size_t)n, 2048)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), param,
-                     grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, bias_corr1, sqrtf(bias_corr2), (size_t)n);
+                     grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, bias_corr1, sqrtf(bias_corr2), (size_t)n,
+                     (const float*)nullptr);
+  CHADA_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- the same three steps with their PER-STEP scalars read from device memory: what a hipGraph of the whole training step needs
+// (a scalar passed by value is frozen into the captured launch; the learning rate, Adam's bias corrections, the EMA tau and the
+// teacher temperature change every step / epoch).  The host writes them to a pinned buffer; the graph's first node copies it over.
+extern "C" int chadavit_adamw_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const float* hyper,
+                                       float beta1, float beta2, float eps, float weight_decay, long long n, void* stream) {
+  CHADA_ENTRY();
+  if (!param || !grad || !exp_avg || !exp_avg_sq || !hyper || n <= 0) return 1;
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((size_t)n, 2048)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), param,
+                     grad, exp_avg, exp_avg_sq, 0.f, beta1, beta2, eps, weight_decay, 1.f, 1.f, (size_t)n, hyper);
+  CHADA_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int chadavit_ema_update_dev(float* teacher, const float* student, const float* tau, long long n, void* stream) {
+  CHADA_ENTRY();
+  if (!teacher || !student || !tau || n <= 0) return 1;
+  if (((uintptr_t)teacher | (uintptr_t)student) & 15) return 2;
+  hipLaunchKernelGGL(ema_kernel, dim3(grid_for((size_t)n / 4 + 1, 2048)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     teacher, student, 0.f, (size_t)n, tau);
+  CHADA_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int chadavit_dino_loss_dev(const float* student, const float* teacher, const float* center, float student_temp,
+                                      const float* teacher_temp, float* loss_rows, chada_bf16* dstudent, float* teacher_colsum, int B,
+                                      int P, void* stream) {
+  CHADA_ENTRY();
+  if (!student || !teacher || !center || !loss_rows || !teacher_temp || B <= 0 || P <= 0 || student_temp <= 0.f) return 1;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(dino_loss_kernel, dim3(B), dim3(256), 0, s, student, teacher, center, 1.0f / student_temp, 0.f, loss_rows,
+                     reinterpret_cast<bf16_t*>(dstudent), B, P, teacher_temp);
+  if (teacher_colsum)
+    hipLaunchKernelGGL(sum_rows_kernel, dim3((P + 63) / 64), dim3(256), 0, s, teacher, teacher_colsum, 2 * B, P, 1.0f,
+                       (int)((P & 3) == 0 && ((uintptr_t)teacher & 15) == 0));
   CHADA_CHECK_LAUNCH();
   return 0;
 }

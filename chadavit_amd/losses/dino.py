@@ -41,6 +41,7 @@ class DINOLoss(nn.Module):
         if num_large_crops != 2:
             raise RuntimeError("DINOLoss: the reference loss is defined over exactly 2 global views (losses/dino.py:87)")
         self.register_buffer("center", torch.zeros(1, num_prototypes))
+        self.temp_dev = None
         self._pending = None       # (event | work, column sum, 1 / (world * rows)) of a centre update in flight
         self._comm_stream = None
         self.teacher_temp_schedule = np.concatenate((
@@ -48,7 +49,9 @@ class DINOLoss(nn.Module):
             np.ones(num_epochs - warmup_teacher_temp_epochs) * teacher_temp))
 
     def forward(self, student_output: torch.Tensor, teacher_output: torch.Tensor) -> torch.Tensor:
-        temp = float(self.teacher_temp_schedule[self.epoch])
+        # temp_dev: a device float32[1] holding the teacher temperature of this epoch (chadavit_amd.graphed: the captured step reads
+        # it from memory instead of freezing the value into the graph)
+        temp = self.temp_dev if self.temp_dev is not None else float(self.teacher_temp_schedule[self.epoch])
         self.sync_center()  # the previous step's centre update (its all-reduce ran beside that step's backward)
         loss, colsum = _DinoLossFn.apply(student_output, teacher_output, self.center, float(self.student_temp), temp)
         self.update_center(teacher_output, colsum)

@@ -622,7 +622,8 @@ def weightnorm_bwd(dw, v, g, inv, dv, accumulate=False):
 
 
 def dino_loss(student, teacher, center, student_temp, teacher_temp, want_grad=True):
-    """Returns (loss_rows [B], dstudent bf16 [2B,P] | None, teacher_colsum [P])."""
+    """Returns (loss_rows [B], dstudent bf16 [2B,P] | None, teacher_colsum [P]).  teacher_temp: a float, or a device float32[1]
+    tensor (read by the kernel: graph-captured training step)."""
     _req(student, F32, "student"); _req(teacher, F32, "teacher"); _req(center, F32, "center")
     B2, P = student.shape
     B = B2 // 2
@@ -630,6 +631,12 @@ def dino_loss(student, teacher, center, student_temp, teacher_temp, want_grad=Tr
     loss_rows = torch.empty((B,), device=dev, dtype=F32)
     dstudent = torch.empty((B2, P), device=dev, dtype=BF16) if want_grad else None
     colsum = torch.empty((P,), device=dev, dtype=F32)
+    if isinstance(teacher_temp, torch.Tensor):
+        _req(teacher_temp, F32, "teacher_temp")
+        rc = lib().chadavit_dino_loss_dev(_ptr(student), _ptr(teacher), _ptr(center), c_float(student_temp), _ptr(teacher_temp),
+                                          _ptr(loss_rows), _ptr(dstudent), _ptr(colsum), c_int(B), c_int(P), _stream())
+        _chk(rc, "chadavit_dino_loss_dev")
+        return loss_rows, dstudent, colsum
     rc = lib().chadavit_dino_loss(_ptr(student), _ptr(teacher), _ptr(center), c_float(student_temp), c_float(teacher_temp),
                                   _ptr(loss_rows), _ptr(dstudent), _ptr(colsum), c_int(B), c_int(P), _stream())
     _chk(rc, "chadavit_dino_loss")
@@ -653,6 +660,21 @@ def sum_rows_f32(x, scale=1.0):
 def ema_update(teacher, student, tau):
     _req(teacher, F32, "teacher"); _req(student, F32, "student")
     _chk(lib().chadavit_ema_update(_ptr(teacher), _ptr(student), c_float(tau), c_ll(teacher.numel()), _stream()), "chadavit_ema_update")
+
+
+def ema_update_dev(teacher, student, tau_dev):
+    """tau read from device memory (one float): for a graph-captured training step."""
+    _req(teacher, F32, "teacher"); _req(student, F32, "student"); _req(tau_dev, F32, "tau_dev")
+    _chk(lib().chadavit_ema_update_dev(_ptr(teacher), _ptr(student), _ptr(tau_dev), c_ll(teacher.numel()), _stream()), "chadavit_ema_update_dev")
+
+
+def adamw_step_dev(param, grad, exp_avg, exp_avg_sq, hyper_dev, beta1, beta2, eps, weight_decay):
+    """hyper_dev: device float32[3] = {lr, 1 - beta1^t, sqrt(1 - beta2^t)} of this step."""
+    _req(param, F32, "param"); _req(grad, F32, "grad"); _req(exp_avg, F32, "exp_avg"); _req(exp_avg_sq, F32, "exp_avg_sq")
+    _req(hyper_dev, F32, "hyper_dev")
+    rc = lib().chadavit_adamw_step_dev(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(hyper_dev), c_float(beta1),
+                                       c_float(beta2), c_float(eps), c_float(weight_decay), c_ll(param.numel()), _stream())
+    _chk(rc, "chadavit_adamw_step_dev")
 
 
 def adamw_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step):

@@ -17,6 +17,58 @@ from . import ops
 from .flat import ALIGN, FlatParams
 
 
+class DeviceHyper:
+    """Per-step AdamW scalars in device memory, for launches that are captured once and replayed (chadavit_amd.graphed).
+
+    One slot = {lr, 1 - beta1^t, sqrt(1 - beta2^t)} for the parameters of one param group that share a step count (the prototypes
+    frozen during epoch 0 lag behind the rest of their group, exactly as torch.optim.AdamW counts steps per parameter).  While an
+    optimizer runs with `device_hyper` set it does NOT advance its per-parameter counters: parameter p is at step
+    `state[p]["step"] + taken`; `advance()` after every (eager or replayed) step, `commit()` to write the counters back."""
+
+    def __init__(self, device, max_slots: int = 16):
+        self.host = torch.zeros(3 * max_slots, dtype=torch.float32).pin_memory()
+        self.dev = torch.zeros(3 * max_slots, dtype=torch.float32, device=device)
+        self.slots: List[tuple] = []   # (group index, step count of the parameters when this object took over)
+        self.taken = 0                 # optimizer steps taken through this object
+        self.active: List = []         # parameters that were stepped through it
+
+    def slot(self, gi: int, p, state) -> torch.Tensor:
+        key = (gi, int(state.get("step", 0)))
+        if key not in self.slots:
+            if 3 * (len(self.slots) + 1) > self.host.numel():
+                raise RuntimeError("DeviceHyper: more (group, step count) classes than slots")
+            self.slots.append(key)
+        if not state.get("dev_active", False):
+            state["dev_active"] = True
+            self.active.append(p)
+        i = self.slots.index(key)
+        return self.dev[3 * i:3 * i + 3]
+
+    def fill(self, optimizer) -> None:
+        """Host values for the NEXT step (read by the graph's first node, a copy host -> dev)."""
+        for i, (gi, step0) in enumerate(self.slots):
+            g = optimizer.param_groups[gi]
+            b1, b2 = g["betas"]
+            t = step0 + self.taken + 1
+            # the same float32 roundings as the by-value path (ops.adamw_step -> chadavit_adamw_step: bias corrections rounded to
+            # float32, then sqrtf in float32), so that a replayed step is bit-identical to an eager one
+            import numpy as np
+            self.host[3 * i] = float(g["lr"])
+            self.host[3 * i + 1] = float(np.float32(1.0 - b1 ** t))
+            self.host[3 * i + 2] = float(np.sqrt(np.float32(1.0 - b2 ** t)))
+
+    def advance(self) -> None:
+        self.taken += 1
+
+    def commit(self, optimizer) -> None:
+        """Write the step counters back (leaving device mode, or before a re-capture with another set of active parameters)."""
+        for p in self.active:
+            st = optimizer.state[p]
+            st["step"] = int(st.get("step", 0)) + self.taken
+            st["dev_active"] = False
+        self.active, self.slots, self.taken = [], [], 0
+
+
 class FusedAdamW(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, modules: Iterable = ()):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
@@ -24,6 +76,10 @@ class FusedAdamW(torch.optim.Optimizer):
         self._modules = list(modules)
         self._slabs: Dict[int, dict] = {}  # id(FlatParams) -> {"m": tensor, "v": tensor}
         self._where: Dict[int, tuple] = {}
+        # device_hyper: a DeviceHyper.  When set, step() launches the kernels that read {lr, bias corrections} from device memory and
+        # leaves the per-parameter step counters to that object (chadavit_amd.graphed.GraphedTrainStep: the launches are captured
+        # once and replayed with new values)
+        self.device_hyper: Optional[DeviceHyper] = None
 
     def _index(self):
         """param id -> (FlatParams, name); rebuilt if a module re-created its slab."""
@@ -45,22 +101,31 @@ class FusedAdamW(torch.optim.Optimizer):
                 loss = closure()
         self._index()
         touched = set()
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             lr, wd, eps = group["lr"], group["weight_decay"], group["eps"]
             b1, b2 = group["betas"]
-            runs: List[list] = []  # [flat, begin, end, step]
+            dh = self.device_hyper
+            runs: List[list] = []  # [flat, begin, end, step | device slot]
             for p in group["params"]:
                 if p.grad is None:
                     continue
                 st = self.state[p]
-                st["step"] = st.get("step", 0) + 1
+                hyper = None
+                if dh is None:
+                    st["step"] = st.get("step", 0) + 1
+                else:
+                    hyper = dh.slot(gi, p, st)
                 loc = self._where.get(id(p))
                 if loc is None:  # parameter outside the flat slabs (e.g. online classifier if it ever gets a gradient)
                     if "exp_avg" not in st:
                         st["exp_avg"] = torch.zeros_like(p, dtype=torch.float32)
                         st["exp_avg_sq"] = torch.zeros_like(p, dtype=torch.float32)
-                    ops.adamw_step(p.data.view(-1), p.grad.contiguous().view(-1), st["exp_avg"].view(-1),
-                                   st["exp_avg_sq"].view(-1), lr, b1, b2, eps, wd, st["step"])
+                    if hyper is not None:
+                        ops.adamw_step_dev(p.data.view(-1), p.grad.contiguous().view(-1), st["exp_avg"].view(-1), st["exp_avg_sq"].view(-1),
+                                           hyper, b1, b2, eps, wd)
+                    else:
+                        ops.adamw_step(p.data.view(-1), p.grad.contiguous().view(-1), st["exp_avg"].view(-1),
+                                       st["exp_avg_sq"].view(-1), lr, b1, b2, eps, wd, st["step"])
                     continue
                 f, n = loc
                 gv = f.g(n)
@@ -68,13 +133,18 @@ class FusedAdamW(torch.optim.Optimizer):
                     gv.copy_(p.grad)
                 beg = f.offsets[n]
                 end = beg + (p.numel() + ALIGN - 1) // ALIGN * ALIGN
-                if runs and runs[-1][0] is f and runs[-1][2] == beg and runs[-1][3] == st["step"]:
+                tag = st["step"] if hyper is None else hyper
+                same = (runs[-1][3] == tag) if (runs and hyper is None) else (runs and runs[-1][3].data_ptr() == tag.data_ptr())
+                if runs and runs[-1][0] is f and runs[-1][2] == beg and same:
                     runs[-1][2] = end
                 else:
-                    runs.append([f, beg, end, st["step"]])
+                    runs.append([f, beg, end, tag])
             for f, beg, end, step in runs:
                 sl = self._slabs[id(f)]
-                ops.adamw_step(f.flat[beg:end], f.grad[beg:end], sl["m"][beg:end], sl["v"][beg:end], lr, b1, b2, eps, wd, step)
+                if dh is not None:
+                    ops.adamw_step_dev(f.flat[beg:end], f.grad[beg:end], sl["m"][beg:end], sl["v"][beg:end], step, b1, b2, eps, wd)
+                else:
+                    ops.adamw_step(f.flat[beg:end], f.grad[beg:end], sl["m"][beg:end], sl["v"][beg:end], lr, b1, b2, eps, wd, step)
                 touched.add(id(f))
         for m in self._modules:
             f = m.flat_params()

@@ -74,7 +74,7 @@ class RaggedBatch:
 
     def use_on_current_stream(self) -> "RaggedBatch":
         """Make the index arrays safe to read from kernels launched on the CURRENT stream (no-op on the uploading stream)."""
-        if self.ready is not None:
+        if self.ready is not None and not torch.cuda.is_current_stream_capturing():  # (a captured step: the upload completed long before)
             cur = torch.cuda.current_stream(self._dev.device)
             if cur != self._alloc_stream:
                 cur.wait_event(self.ready)

@@ -43,13 +43,17 @@ class MomentumUpdater:
         self.base_tau = base_tau
         self.cur_tau = base_tau
         self.final_tau = final_tau
+        self.tau_dev = None   # device float32[1]: when set, the EMA kernel reads tau from it (graph-captured step)
 
     @torch.no_grad()
     def update(self, online_net: nn.Module, momentum_net: nn.Module):
         """theta_t <- tau*theta_t + (1-tau)*theta_s for every parameter pair (momentum.py:63-74)."""
         fo, fm = _flat_of(online_net), _flat_of(momentum_net)
         if fo is not None and fm is not None and fo.numel == fm.numel and fo.names == fm.names:
-            ops.ema_update(fm.flat, fo.flat, float(self.cur_tau))
+            if self.tau_dev is not None:
+                ops.ema_update_dev(fm.flat, fo.flat, self.tau_dev)
+            else:
+                ops.ema_update(fm.flat, fo.flat, float(self.cur_tau))
             fm.mark_dirty()
             return
         for op, mp in zip(online_net.parameters(), momentum_net.parameters()):

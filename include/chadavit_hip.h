@@ -213,6 +213,16 @@ int chadavit_ema_update(float* teacher, const float* student, float tau, long lo
 int chadavit_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
                         float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2, long long n,
                         void* stream);
+/* The per-step scalars of the three launches above read from DEVICE memory instead of being passed by value, so that a hipGraph of
+ * the whole training step (chadavit_amd.graphed.GraphedTrainStep) can be replayed with a new learning rate / bias correction / tau /
+ * temperature each step:  hyper = {lr, 1 - beta1^t, sqrt(1 - beta2^t)};  tau, teacher_temp = one float each.
+ * replaces the same reference lines as their by-value twins (base.py:67-72, momentum.py:63-74, losses/dino.py:69-118). */
+int chadavit_adamw_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const float* hyper, float beta1,
+                            float beta2, float eps, float weight_decay, long long n, void* stream);
+int chadavit_ema_update_dev(float* teacher, const float* student, const float* tau, long long n, void* stream);
+int chadavit_dino_loss_dev(const float* student, const float* teacher, const float* center, float student_temp,
+                           const float* teacher_temp, float* loss_rows, chada_bf16* dstudent, float* teacher_colsum, int B, int P,
+                           void* stream);
 /* Per-channel intensity jitter of the collated crop tensor x [n_channel_images, 1, S, S] fp32, in place:
  * x <- clamp(gamma_c * (x + shift_c), 0, 1) (CustomColorJitter.apply, src/data/custom_transforms.py:301-351), with an
  * optional per-channel-image horizontal flip (flip may be NULL) in the same pass. */

@@ -863,3 +863,53 @@ def test_crop_buffer_modified_between_forward_and_backward_is_detected():
     out = m.forward_ragged(x, [3, 1])
     out.sum().backward()   # untouched buffer: fine
     assert torch.isfinite(m.token_learner.proj.weight.grad).all()
+
+
+@pytest.mark.parametrize("n_small", [0, 2])
+def test_graphed_train_step_matches_eager(n_small):
+    """chadavit_amd.graphed.GraphedTrainStep (the whole training step as one hipGraph, device-resident LR / bias corrections / tau /
+    teacher temperature) against Trainer.train_step on the same batches: same kernels in the same order, so the losses, the
+    student, the EMA teacher, the centre, Adam's moments and the schedules must come out IDENTICAL -- across the epoch boundary
+    where the prototypes unfreeze (a second graph: other parameters are active, their Adam step counters lag) and the teacher
+    temperature moves."""
+    from chadavit_amd.data.channels_strategies import one_channel_collate_fn
+    from chadavit_amd.graphed import GraphedTrainStep
+    from chadavit_amd.methods.dino import DINO
+    from chadavit_amd.trainer import Trainer
+    dev = _dev()
+    nch = [1, 1, 2, 1]
+    sizes = [224, 224] + [96] * n_small
+    batches = []
+    for s_ in range(6):
+        crops, labels, ncl = one_channel_collate_fn(P.make_images(nch, sizes, seed=300 + s_))
+        crops = crops if isinstance(crops, list) else [crops]
+        batches.append(([c.to(dev) for c in crops], labels.to(dev), ncl if isinstance(ncl[0], list) else [ncl]))
+    runs = {}
+    for mode in ("eager", "graph"):
+        cfg = _cfg(192, 4096, 2, n_small)
+        cfg.method_kwargs.warmup_teacher_temperature_epochs = 3
+        model = DINO(cfg)
+        model.load_state_dict(build_sd(192, 4096))
+        model = model.to(dev)
+        tr = Trainer(max_epochs=4, steps_per_epoch=3).attach(model)
+        step = GraphedTrainStep(tr) if mode == "graph" else tr.train_step
+        losses = []
+        for i, b in enumerate(batches):
+            tr.current_epoch = i // 3
+            losses.append(float(step(b, i % 3).item()))
+        if mode == "graph":
+            assert len(step.graphs) == 2   # frozen / unfrozen prototypes
+            step.close()
+        torch.cuda.synchronize()
+        opt = tr.optimizer
+        runs[mode] = {"losses": losses, "sd": {k: v.clone() for k, v in model.state_dict().items()},
+                      "m": [sl["m"].clone() for sl in opt._slabs.values()], "tau": model.momentum_updater.cur_tau,
+                      "lr": [g["lr"] for g in opt.param_groups], "gs": tr.global_step,
+                      "steps": sorted({int(st.get("step", 0)) for st in opt.state.values() if "step" in st})}
+    e, g = runs["eager"], runs["graph"]
+    assert e["gs"] == g["gs"] == 6 and e["tau"] == g["tau"] and e["lr"] == g["lr"] and e["steps"] == g["steps"] == [3, 6]
+    assert e["losses"] == g["losses"], (e["losses"], g["losses"])
+    for k, v in e["sd"].items():
+        assert torch.equal(v, g["sd"][k]), k
+    for a, b in zip(e["m"], g["m"]):
+        assert torch.equal(a, b)
