@@ -219,41 +219,32 @@ class DeviceMultiCropPipeline:
         return crops, lab, [list(nch) for _ in crops]
 
     def _run_crop(self, spec: CropSpec, cp: CropParams, src, shapes, offs, out=None) -> torch.Tensor:
+        """Per-channel-image descriptor tables for the two kernels, built with numpy (a Python loop over the ~1500 channel images of
+        a 512-image batch, ten crops per batch, was the slowest stage of the whole data path)."""
         S = spec.crop_size
-        desc, shift, gamma, fin = [], [], [], []
-        any_jit = any(s is not None for s in cp.shifts)
-        normed = cp.normalized if cp.normalized else [spec.normalize is not None] * len(shapes)
-        grays = cp.grays if cp.grays else [False] * len(shapes)
-        any_fin = any(normed) or any(b is not None for b in cp.blurs) or any(t is not None for t in cp.solarize)
-        for i, (C, H, W) in enumerate(shapes):
-            y0, x0, h, w = cp.boxes[i]
-            for c in range(C):
-                desc.append([offs[i] + c * H * W, H, W, x0, y0, w, h, 1 if cp.flips[i] else 0])
-                if any_jit:
-                    shift.append(0.0 if cp.shifts[i] is None else float(cp.shifts[i][c]))
-                    gamma.append(-1.0 if cp.gammas[i] is None else float(cp.gammas[i][c]))
-                if any_fin:
-                    row = np.zeros(12, dtype=np.float32)
-                    if cp.blurs[i] is not None and cp.blurs[i][0] > 1:
-                        k, sg = cp.blurs[i]
-                        if k > 7:
-                            raise RuntimeError("GaussianBlur kernel sizes above 7 are not supported on the device path")
-                        row[0] = k
-                        row[1:8] = gaussian_taps(k, sg)
-                    row[8] = np.inf if cp.solarize[i] is None else cp.solarize[i]
-                    row[9] = spec.solarize_max
-                    if normed[i]:
-                        mean, std, mpv = spec.normalize
-                        row[10] = float(mean[c % len(mean)]) * mpv
-                        row[11] = 1.0 / (float(std[c % len(std)]) * mpv)
-                    else:
-                        row[10], row[11] = 0.0, 1.0
-                    fin.append(row)
+        n = len(shapes)
+        C = np.fromiter((s_[0] for s_ in shapes), dtype=np.int64, count=n)
+        H = np.fromiter((s_[1] for s_ in shapes), dtype=np.int64, count=n)
+        W = np.fromiter((s_[2] for s_ in shapes), dtype=np.int64, count=n)
+        off = np.asarray(offs, dtype=np.int64)
+        normed = np.asarray(cp.normalized if cp.normalized else [spec.normalize is not None] * n, dtype=bool)
+        grays = cp.grays if cp.grays else [False] * n
+        has_blur = np.fromiter((b is not None and b[0] > 1 for b in cp.blurs), dtype=bool, count=n)
+        has_sol = np.fromiter((t is not None for t in cp.solarize), dtype=bool, count=n)
+        any_jit = any(s_ is not None for s_ in cp.shifts)
+        any_fin = bool(normed.any() or has_blur.any() or has_sol.any())
+        rep = lambda a: np.repeat(a, C)                                   # per sample -> per channel image
+        chan = np.concatenate([np.arange(c) for c in C])                  # channel index inside its sample
+        box = np.asarray(cp.boxes, dtype=np.int64).reshape(n, 4)          # (y0, x0, h, w)
+        desc = np.stack([rep(off) + chan * rep(H * W), rep(H), rep(W), rep(box[:, 1]), rep(box[:, 0]), rep(box[:, 3]), rep(box[:, 2]),
+                         rep(np.asarray(cp.flips, dtype=np.int64))], axis=1)
         dev = self.device
-        d = torch.tensor(desc, dtype=torch.int64).to(dev)
+        d = torch.from_numpy(desc).to(dev, non_blocking=True)
         first = None if any_fin else out   # the finishing pass reads the resized planes and writes the caller's buffer
         if any_jit:   # gamma = -1 marks the channel images whose sample did not draw the jitter (no clamp for them)
-            res = ops.crop_resize(src, d, S, torch.tensor(shift, dtype=torch.float32).to(dev), torch.tensor(gamma, dtype=torch.float32).to(dev),
+            shift = np.concatenate([np.zeros(c, np.float32) if s_ is None else np.asarray(s_, np.float32) for c, s_ in zip(C, cp.shifts)])
+            gamma = np.concatenate([np.full(c, -1.0, np.float32) if g_ is None else np.asarray(g_, np.float32) for c, g_ in zip(C, cp.gammas)])
+            res = ops.crop_resize(src, d, S, torch.from_numpy(shift).to(dev, non_blocking=True), torch.from_numpy(gamma).to(dev, non_blocking=True),
                                   out=first)
         else:
             res = ops.crop_resize(src, d, S, out=first)
@@ -263,10 +254,31 @@ class DeviceMultiCropPipeline:
             # with the flip fused into the resize pass.  Plain tensor arithmetic on three planes per firing sample.
             w = torch.tensor([0.299, 0.587, 0.114], device=dev, dtype=torch.float32).view(3, 1, 1, 1)
             c0 = 0
-            for i, (C, H, W) in enumerate(shapes):
+            for i in range(n):
                 if grays[i]:
                     res[c0:c0 + 3] = (res[c0:c0 + 3] * w).sum(0, keepdim=True)
-                c0 += C
+                c0 += int(C[i])
         if any_fin:
-            res = ops.blur_finish(res, torch.from_numpy(np.stack(fin)).to(dev), out=out)
+            fin = np.zeros((int(C.sum()), 12), dtype=np.float32)
+            fin[:, 8] = np.inf
+            fin[:, 9] = spec.solarize_max
+            fin[:, 11] = 1.0
+            if has_blur.any():
+                rows = np.zeros((n, 8), dtype=np.float32)
+                for i in np.nonzero(has_blur)[0]:
+                    k, sg = cp.blurs[i]
+                    if k > 7:
+                        raise RuntimeError("GaussianBlur kernel sizes above 7 are not supported on the device path")
+                    rows[i, 0] = k
+                    rows[i, 1:8] = gaussian_taps(k, sg)
+                fin[:, 0:8] = np.repeat(rows, C, axis=0)
+            if has_sol.any():
+                fin[:, 8] = rep(np.asarray([np.inf if t is None else t for t in cp.solarize], dtype=np.float32))
+            if normed.any():
+                mean, std, mpv = spec.normalize
+                mean, std = np.asarray(mean, np.float32), np.asarray(std, np.float32)
+                on = rep(normed)
+                fin[on, 10] = (mean[chan % len(mean)] * mpv)[on]
+                fin[on, 11] = (1.0 / (std[chan % len(std)] * mpv))[on]
+            res = ops.blur_finish(res, torch.from_numpy(fin).to(dev, non_blocking=True), out=out)
         return res

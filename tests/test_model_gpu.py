@@ -160,9 +160,32 @@ def test_fp8_weight_path_vs_golden():
     tot_h = sum(named[str(n)].grad.double().norm().item() ** 2 for n in g["grad_names"]) ** 0.5
     tot_r = float(np.sqrt((g["grad_norms"] ** 2).sum()))
     print("fp8 step_base_c10: loss", loss.item(), "vs", float(g["loss"]), "grad norm", tot_h, "vs", tot_r)
-    assert abs(tot_h - tot_r) <= 0.15 * tot_r, (tot_h, tot_r)   # fp8 forward activations feed a bf16 backward
-    for key in ("backbone.norm.weight", "head.mlp.4.bias"):
-        assert _cos(named[key].grad, torch.from_numpy(g["grad::" + key])) >= 0.95, key
+    # fp8 gradient bar (SURVEY 8(c) states none for this path; stated here): fp8 forward activations feed a bf16 backward --
+    #   global gradient norm rel <= 5e-2 (measured 2.7e-2); EVERY tensor's norm rel <= 0.10 (tensors carrying >= 1e-3 of the largest
+    #   norm; measured worst 6.7e-2, blocks.7.norm2.weight); cosine >= 0.93 on every tensor the golden holds in full (measured lowest
+    #   0.941: cls_token, a single D-vector; the matrices are >= 0.98)
+    _fp8_gradient_bar(named, g, "fp8 step_base_c10")
+
+
+def _fp8_gradient_bar(named, g, tag, norm_rel_global=5e-2, norm_rel_tensor=0.10, cos_min=0.93):
+    names = [str(n) for n in g["grad_names"]]
+    ref_norms = {n: float(v) for n, v in zip(names, g["grad_norms"])}
+    tot_h = sum(named[n].grad.double().norm().item() ** 2 for n in names) ** 0.5
+    tot_r = float(np.sqrt(sum(v * v for v in ref_norms.values())))
+    big = max(ref_norms.values())
+    worst_n, worst_c = (0.0, None), (1.0, None)
+    for n in names:
+        if ref_norms[n] >= 1e-3 * big:
+            rel = abs(named[n].grad.double().norm().item() - ref_norms[n]) / ref_norms[n]
+            worst_n = max(worst_n, (rel, n))
+        if "grad::" + n in g.files:
+            c = _cos(named[n].grad, torch.from_numpy(g["grad::" + n]))
+            worst_c = min(worst_c, (c, n))
+    print(f"{tag}: grad norm {tot_h:.5f} vs {tot_r:.5f}; worst per-tensor norm rel {worst_n}; lowest cosine {worst_c} "
+          f"over {sum(1 for n in names if 'grad::' + n in g.files)} full tensors")
+    assert abs(tot_h - tot_r) <= norm_rel_global * tot_r, (tot_h, tot_r)
+    assert worst_n[0] <= norm_rel_tensor, worst_n
+    assert worst_c[0] >= cos_min, worst_c
 
 
 def test_backbone_errors_and_surface():
@@ -377,12 +400,7 @@ def test_bench_scale_replicated_batch_vs_golden(name, R_, rows, weight_dtype):
     if fp8:
         assert sum(v["launches"] for k, v in summ.items() if k[0] == "gemm_nt_mx8" and k[1] == rows) == (4 * 11 + 1) * 2   # last block: QKV only
         assert abs(loss.item() - float(g["loss"])) <= 5e-2, (loss.item(), float(g["loss"]))
-        named = dict(model.named_parameters())
-        tot_h = sum(named[str(n)].grad.double().norm().item() ** 2 for n in g["grad_names"]) ** 0.5
-        tot_r = float(np.sqrt((g["grad_norms"] ** 2).sum()))
-        assert abs(tot_h - tot_r) <= 0.15 * tot_r, (tot_h, tot_r)   # fp8 forward activations feed a bf16 backward
-        for key in ("backbone.norm.weight", "head.mlp.4.bias"):
-            assert _cos(named[key].grad, torch.from_numpy(g["grad::" + key])) >= 0.95, key
+        _fp8_gradient_bar(dict(model.named_parameters()), g, f"fp8 {name} x {R_}")
         return
     assert abs(loss.item() - float(g["loss"])) <= 2e-2, (loss.item(), float(g["loss"]))
     loss_o, grads_o, newc_o, aux = R.training_step(sd, crops_s, ncl_s, n_large, float(g["teacher_temp"]), freeze_last_layer=epoch < 1,
