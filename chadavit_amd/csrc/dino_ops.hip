@@ -204,17 +204,32 @@ __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ t, const f
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, float lr, float b1, float b2, float eps, float wd,
-                                                    float bc1, float bc2_sqrt, size_t n, const float* __restrict__ hyper) {
+                                                    float bc1, float bc2_sqrt, size_t n, const float* __restrict__ hyper, int l2) {
   if (hyper) { lr = hyper[0]; bc1 = hyper[1]; bc2_sqrt = hyper[2]; }  // {lr, 1 - beta1^t, sqrt(1 - beta2^t)} of this step, on the device
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const float gg = g[i];
-    float pp = p[i] * (1.0f - lr * wd);
+    // l2 = 0: AdamW (decoupled decay of the parameter);  l2 = 1: torch.optim.Adam (the decay enters the gradient: g + wd p)
+    const float gg = l2 ? g[i] + wd * p[i] : g[i];
+    float pp = l2 ? p[i] : p[i] * (1.0f - lr * wd);
     const float mm = b1 * m[i] + (1.0f - b1) * gg;
     const float vv = b2 * v[i] + (1.0f - b2) * gg * gg;
     m[i] = mm;
     v[i] = vv;
     const float denom = sqrtf(vv) / bc2_sqrt + eps;
     p[i] = pp - (lr / bc1) * mm / denom;
+  }
+}
+
+// torch.optim.SGD: d = g + wd p;  buf = first ? d : mu buf + (1 - dampening) d;  d = nesterov ? d + mu buf : buf;  p -= lr d
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, float lr,
+                                                  float mu, float dampening, float wd, int nesterov, int first, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float d = g[i] + wd * p[i];
+    if (mu != 0.f) {
+      const float b = first ? d : mu * buf[i] + (1.0f - dampening) * d;
+      buf[i] = b;
+      d = nesterov ? d + mu * b : b;
+    }
+    p[i] -= lr * d;
   }
 }
 
@@ -518,7 +533,29 @@ extern "C" int chadavit_adamw_step(float* param, const float* grad, float* exp_a
   if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || bias_corr1 <= 0.f || bias_corr2 <= 0.f) return 1;
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((size_t)n, 2048)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), param,
                      grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, bias_corr1, sqrtf(bias_corr2), (size_t)n,
-                     (const float*)nullptr);
+                     (const float*)nullptr, 0);
+  CHADA_CHECK_LAUNCH();
+  return 0;
+}
+// torch.optim.Adam (base.py:67-72 "adam"): as above with the weight decay added to the gradient instead of decaying the parameter
+extern "C" int chadavit_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
+                                  float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2, long long n,
+                                  void* stream) {
+  CHADA_ENTRY();
+  if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || bias_corr1 <= 0.f || bias_corr2 <= 0.f) return 1;
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((size_t)n, 2048)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), param,
+                     grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, bias_corr1, sqrtf(bias_corr2), (size_t)n,
+                     (const float*)nullptr, 1);
+  CHADA_CHECK_LAUNCH();
+  return 0;
+}
+// torch.optim.SGD (base.py:67-72 "sgd"); momentum_buf may be NULL when momentum == 0; first = 1 on a parameter's first step
+extern "C" int chadavit_sgd_step(float* param, const float* grad, float* momentum_buf, float lr, float momentum, float dampening,
+                                 float weight_decay, int nesterov, int first, long long n, void* stream) {
+  CHADA_ENTRY();
+  if (!param || !grad || n <= 0 || (momentum != 0.f && !momentum_buf)) return 1;
+  hipLaunchKernelGGL(sgd_kernel, dim3(grid_for((size_t)n, 2048)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), param, grad,
+                     momentum_buf, lr, momentum, dampening, weight_decay, nesterov, first, (size_t)n);
   CHADA_CHECK_LAUNCH();
   return 0;
 }
@@ -531,7 +568,7 @@ extern "C" int chadavit_adamw_step_dev(float* param, const float* grad, float* e
   CHADA_ENTRY();
   if (!param || !grad || !exp_avg || !exp_avg_sq || !hyper || n <= 0) return 1;
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((size_t)n, 2048)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), param,
-                     grad, exp_avg, exp_avg_sq, 0.f, beta1, beta2, eps, weight_decay, 1.f, 1.f, (size_t)n, hyper);
+                     grad, exp_avg, exp_avg_sq, 0.f, beta1, beta2, eps, weight_decay, 1.f, 1.f, (size_t)n, hyper, 0);
   CHADA_CHECK_LAUNCH();
   return 0;
 }

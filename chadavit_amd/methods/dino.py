@@ -361,9 +361,9 @@ class DINO(_Base):
 
     def configure_optimizers(self):
         """AdamW on the flat slabs + per-step warmup-cosine LR (base.py:416-492; lr_scheduler.py:76-125)."""
-        from ..optim import FusedAdamW, FusedLARS, WarmupCosineLR, remove_bias_and_norm_from_weight_decay
-        if self.optimizer not in ("adamw", "lars"):
-            raise RuntimeError("chadavit_amd ships fused AdamW and LARS (sgd / adam of base.py:67-72 are not on the DINO configs)")
+        from ..optim import FusedAdam, FusedAdamW, FusedLARS, FusedSGD, WarmupCosineLR, remove_bias_and_norm_from_weight_decay
+        if self.optimizer not in ("adamw", "lars", "adam", "sgd"):   # base.py:67-72 _OPTIMIZERS
+            raise RuntimeError(f"optimizer {self.optimizer} not in (sgd, lars, adam, adamw)")
         groups = []
         for g in self.learnable_params:
             g = dict(g)
@@ -372,10 +372,13 @@ class DINO(_Base):
         if self.exclude_bias_n_norm_wd:
             groups = remove_bias_and_norm_from_weight_decay(groups)
         kw = dict(self.extra_optimizer_args)
-        if self.optimizer == "adamw":
+        if self.optimizer in ("adamw", "adam"):
             if "betas" in kw:
                 kw["betas"] = tuple(kw["betas"])
-            opt = FusedAdamW(groups, lr=self.lr, weight_decay=self.weight_decay, modules=[self.backbone, self.head], **kw)
+            cls = FusedAdamW if self.optimizer == "adamw" else FusedAdam
+            opt = cls(groups, lr=self.lr, weight_decay=self.weight_decay, modules=[self.backbone, self.head], **kw)
+        elif self.optimizer == "sgd":
+            opt = FusedSGD(groups, lr=self.lr, weight_decay=self.weight_decay, modules=[self.backbone, self.head], **kw)
         else:
             opt = FusedLARS(groups, lr=self.lr, weight_decay=self.weight_decay, modules=[self.backbone, self.head], **kw)
         if str(self.scheduler).lower() == "none":

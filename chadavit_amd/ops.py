@@ -687,6 +687,25 @@ def adamw_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_d
     _chk(rc, "chadavit_adamw_step")
 
 
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step):
+    """torch.optim.Adam's update (L2 weight decay inside the gradient)."""
+    _req(param, F32, "param"); _req(grad, F32, "grad"); _req(exp_avg, F32, "exp_avg"); _req(exp_avg_sq, F32, "exp_avg_sq")
+    rc = lib().chadavit_adam_step(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), c_float(lr), c_float(beta1), c_float(beta2),
+                                  c_float(eps), c_float(weight_decay), c_float(1.0 - beta1 ** step), c_float(1.0 - beta2 ** step),
+                                  c_ll(param.numel()), _stream())
+    _chk(rc, "chadavit_adam_step")
+
+
+def sgd_step(param, grad, buf, lr, momentum, dampening, weight_decay, nesterov, first):
+    """torch.optim.SGD's update; buf (momentum buffer) may be None when momentum == 0."""
+    _req(param, F32, "param"); _req(grad, F32, "grad")
+    if buf is not None:
+        _req(buf, F32, "buf")
+    rc = lib().chadavit_sgd_step(_ptr(param), _ptr(grad), _ptr(buf), c_float(lr), c_float(momentum), c_float(dampening),
+                                 c_float(weight_decay), c_int(1 if nesterov else 0), c_int(1 if first else 0), c_ll(param.numel()), _stream())
+    _chk(rc, "chadavit_sgd_step")
+
+
 def lars_step(params, grads, bufs, offsets, sizes, flags, lr, momentum, dampening, weight_decay, eta, eps, clip_lr, nesterov):
     _req(params, F32, "params"); _req(grads, F32, "grads"); _req(bufs, F32, "bufs")
     _req(offsets, I64, "offsets"); _req(sizes, I64, "sizes"); _req(flags, I32, "flags")

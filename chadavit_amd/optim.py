@@ -70,6 +70,8 @@ class DeviceHyper:
 
 
 class FusedAdamW(torch.optim.Optimizer):
+    decoupled = True   # AdamW; FusedAdam below: torch.optim.Adam's L2 form
+
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, modules: Iterable = ()):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
@@ -105,6 +107,9 @@ class FusedAdamW(torch.optim.Optimizer):
             lr, wd, eps = group["lr"], group["weight_decay"], group["eps"]
             b1, b2 = group["betas"]
             dh = self.device_hyper
+            if dh is not None and not self.decoupled:
+                raise RuntimeError("device-resident hyper-parameters (GraphedTrainStep) are built for AdamW")
+            step_fn = ops.adamw_step if self.decoupled else ops.adam_step
             runs: List[list] = []  # [flat, begin, end, step | device slot]
             for p in group["params"]:
                 if p.grad is None:
@@ -124,8 +129,8 @@ class FusedAdamW(torch.optim.Optimizer):
                         ops.adamw_step_dev(p.data.view(-1), p.grad.contiguous().view(-1), st["exp_avg"].view(-1), st["exp_avg_sq"].view(-1),
                                            hyper, b1, b2, eps, wd)
                     else:
-                        ops.adamw_step(p.data.view(-1), p.grad.contiguous().view(-1), st["exp_avg"].view(-1),
-                                       st["exp_avg_sq"].view(-1), lr, b1, b2, eps, wd, st["step"])
+                        step_fn(p.data.view(-1), p.grad.contiguous().view(-1), st["exp_avg"].view(-1),
+                                st["exp_avg_sq"].view(-1), lr, b1, b2, eps, wd, st["step"])
                     continue
                 f, n = loc
                 gv = f.g(n)
@@ -144,7 +149,81 @@ class FusedAdamW(torch.optim.Optimizer):
                 if dh is not None:
                     ops.adamw_step_dev(f.flat[beg:end], f.grad[beg:end], sl["m"][beg:end], sl["v"][beg:end], step, b1, b2, eps, wd)
                 else:
-                    ops.adamw_step(f.flat[beg:end], f.grad[beg:end], sl["m"][beg:end], sl["v"][beg:end], lr, b1, b2, eps, wd, step)
+                    step_fn(f.flat[beg:end], f.grad[beg:end], sl["m"][beg:end], sl["v"][beg:end], lr, b1, b2, eps, wd, step)
+                touched.add(id(f))
+        for m in self._modules:
+            f = m.flat_params()
+            if id(f) in touched:
+                f.mark_dirty()
+        return loss
+
+
+class FusedAdam(FusedAdamW):
+    """torch.optim.Adam (the reference's "adam", base.py:67-72): weight decay as an L2 term of the gradient; defaults as torch's."""
+    decoupled = False
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, modules: Iterable = ()):
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, modules=modules)
+
+
+class FusedSGD(torch.optim.Optimizer):
+    """torch.optim.SGD (the reference's "sgd", base.py:67-72) over the flat slabs: one launch per run of consecutive parameters that
+    share a step count.  Momentum buffers live in a slab of the parameters' layout."""
+
+    def __init__(self, params, lr=1e-3, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False, modules: Iterable = ()):
+        if nesterov and (momentum <= 0 or dampening != 0):
+            raise ValueError("Nesterov momentum requires a momentum and zero dampening")
+        super().__init__(params, dict(lr=lr, momentum=momentum, dampening=dampening, weight_decay=weight_decay, nesterov=nesterov))
+        self._modules = list(modules)
+        self._bufs: Dict[int, torch.Tensor] = {}
+        self._where: Dict[int, tuple] = {}
+
+    def _index(self):
+        flats = [m.flat_params() for m in self._modules]
+        if self._where and all(id(f) in self._bufs for f in flats):
+            return
+        self._where = {}
+        for f in flats:
+            self._bufs.setdefault(id(f), torch.zeros_like(f.flat))
+            for n, p in zip(f.names, f.params):
+                self._where[id(p)] = (f, n)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        self._index()
+        touched = set()
+        for group in self.param_groups:
+            lr, mu, damp, wd, nest = group["lr"], group["momentum"], group["dampening"], group["weight_decay"], group["nesterov"]
+            runs: List[list] = []  # [flat, begin, end, first]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                first = "seen" not in st
+                st["seen"] = True
+                loc = self._where.get(id(p))
+                if loc is None:
+                    if mu != 0 and "momentum_buffer" not in st:
+                        st["momentum_buffer"] = torch.zeros_like(p, dtype=torch.float32)
+                    ops.sgd_step(p.data.view(-1), p.grad.contiguous().view(-1), st["momentum_buffer"].view(-1) if mu != 0 else None, lr, mu, damp,
+                                 wd, nest, first)
+                    continue
+                f, n = loc
+                gv = f.g(n)
+                if p.grad.data_ptr() != gv.data_ptr():
+                    gv.copy_(p.grad)
+                beg = f.offsets[n]
+                end = beg + (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+                if runs and runs[-1][0] is f and runs[-1][2] == beg and runs[-1][3] == first:
+                    runs[-1][2] = end
+                else:
+                    runs.append([f, beg, end, first])
+            for f, beg, end, first in runs:
+                ops.sgd_step(f.flat[beg:end], f.grad[beg:end], self._bufs[id(f)][beg:end] if mu != 0 else None, lr, mu, damp, wd, nest, first)
                 touched.add(id(f))
         for m in self._modules:
             f = m.flat_params()

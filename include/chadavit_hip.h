@@ -213,6 +213,12 @@ int chadavit_ema_update(float* teacher, const float* student, float tau, long lo
 int chadavit_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
                         float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2, long long n,
                         void* stream);
+/* The reference's other two optimiser choices (base.py:67-72 `_OPTIMIZERS`): torch.optim.Adam (weight decay added to the gradient) and
+ * torch.optim.SGD (momentum / dampening / Nesterov), each one launch over a run of the flat parameter slab. */
+int chadavit_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1, float beta2,
+                       float eps, float weight_decay, float bias_corr1, float bias_corr2, long long n, void* stream);
+int chadavit_sgd_step(float* param, const float* grad, float* momentum_buf, float lr, float momentum, float dampening,
+                      float weight_decay, int nesterov, int first, long long n, void* stream);
 /* The per-step scalars of the three launches above read from DEVICE memory instead of being passed by value, so that a hipGraph of
  * the whole training step (chadavit_amd.graphed.GraphedTrainStep) can be replayed with a new learning rate / bias correction / tau /
  * temperature each step:  hyper = {lr, 1 - beta1^t, sqrt(1 - beta2^t)};  tau, teacher_temp = one float each.

@@ -554,6 +554,32 @@ def test_flat_param_kernels():
         assert torch.equal(ops.sum_rows_f32(x), ops.sum_rows_f32(x)), "sum_rows must be deterministic"
 
 
+@pytest.mark.parametrize("kind,kw", [("adam", dict(lr=1e-3, weight_decay=1e-2)), ("adam", dict(lr=3e-3, betas=(0.8, 0.99), eps=1e-6, weight_decay=0.0)),
+                                      ("sgd", dict(lr=0.05, weight_decay=1e-3)), ("sgd", dict(lr=0.05, momentum=0.9, weight_decay=1e-3)),
+                                      ("sgd", dict(lr=0.05, momentum=0.9, dampening=0.1)), ("sgd", dict(lr=0.05, momentum=0.9, nesterov=True, weight_decay=1e-2))])
+def test_fused_adam_and_sgd_match_torch_optim(kind, kw):
+    """The reference's other optimiser choices (base.py:67-72: torch.optim.Adam / torch.optim.SGD) as one launch per slab run, through
+    the module's own `configure_optimizers` plumbing (FlatParams slabs, parameters that receive no gradient are skipped): four steps
+    against torch.optim on a copy of the same parameters and gradients."""
+    from chadavit_amd.optim import FusedAdam, FusedSGD
+    dev = _dev()
+    m = torch.nn.Sequential(torch.nn.Linear(37, 53), torch.nn.LayerNorm(53), torch.nn.Linear(53, 11)).to(dev)
+    ref = [p.detach().clone().requires_grad_(True) for p in m.parameters()]
+    params = list(m.parameters())
+    fused = (FusedAdam if kind == "adam" else FusedSGD)([{"params": params[:2]}, {"params": params[2:], "weight_decay": 0.0}], **kw)
+    topt = (torch.optim.Adam if kind == "adam" else torch.optim.SGD)([{"params": ref[:2]}, {"params": ref[2:], "weight_decay": 0.0}], **kw)
+    for step in range(4):
+        for i, (p, r) in enumerate(zip(params, ref)):
+            g = _rand(tuple(p.shape), 400 + 10 * step + i, 0.3).to(dev)
+            skip = (i == 3 and step < 2)   # a parameter without a gradient for the first steps (frozen prototypes): its counters lag
+            p.grad = None if skip else g.clone()
+            r.grad = None if skip else g.clone()
+        fused.step()
+        topt.step()
+    for p, r in zip(params, ref):
+        _close(p.detach(), r.detach(), 2e-6, 2e-6, f"{kind} {kw}")
+
+
 def test_layernorm_fwd2_is_two_layernorms():
     from chadavit_amd import ops
     dev = _dev()
