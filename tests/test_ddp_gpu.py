@@ -174,7 +174,8 @@ sd = model.state_dict()
 out = {"rank": rank, "losses": losses, "seen": seen, "steps": len(losses),
        "w": sd["backbone.blocks.3.linear1.weight"].double().sum().item(), "wt": sd["momentum_backbone.blocks.3.linear1.weight"].double().sum().item(),
        "center": sd["dino_loss_func.center"].double().sum().item(), "logged": model.logged_metrics().get("dino_loss_train")}
-print("RESULT " + json.dumps(out), flush=True)
+with open(os.path.join(os.environ["CHADAVIT_OUT"], f"rank{rank}.json"), "w") as f:   # (stdout of the two ranks can interleave)
+    json.dump(out, f)
 if world > 1:
     dist.barrier(); dist.destroy_process_group()
 '''
@@ -203,16 +204,17 @@ def test_disk_to_training_step_on_two_ranks(tmp_path):
                 paths.append(rel)
             f.write(f'id{i},"{paths}"\n')
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    env = dict(os.environ, CHADAVIT_ROOT=ROOT, PYTHONPATH=ROOT, CHADAVIT_DATA=str(root), CHADAVIT_DIST_BACKEND="gloo", CHADAVIT_SINGLE_DEVICE="1")
     tmpdir = tempfile.mkdtemp(prefix="chadavit_data_")
+    env = dict(os.environ, CHADAVIT_ROOT=ROOT, PYTHONPATH=ROOT, CHADAVIT_DATA=str(root), CHADAVIT_DIST_BACKEND="gloo", CHADAVIT_SINGLE_DEVICE="1",
+               CHADAVIT_OUT=tmpdir)
     path = os.path.join(tmpdir, "_data_worker.py")
     with open(path, "w") as f:
         f.write(DATA_WORKER)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), path]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=800)
-    res = [json.loads(l[7:]) for l in r.stdout.splitlines() if l.startswith("RESULT ")]
-    assert r.returncode == 0 and len(res) == 2, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
+    assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
+    res = [json.load(open(os.path.join(tmpdir, f"rank{k}.json"))) for k in range(2)]
     a, b = sorted(res, key=lambda d: d["rank"])
     assert a["steps"] == b["steps"] == 2 and all(np.isfinite(a["losses"] + b["losses"]))
     for sa, sb in zip(a["seen"], b["seen"]):   # a global batch of 8: four images per rank, disjoint

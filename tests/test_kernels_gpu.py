@@ -240,7 +240,7 @@ def test_layernorm_bwd_pair_equals_two_calls(T, D, acc):
     e2 = (dz2.float() - dz.float()).abs()
     assert bool((e2 <= 2 ** -7 * dz.float().abs() + 2e-3 * float(dz.float().abs().max())).all()) and float((e2 > 0).float().mean()) < 0.01, float(e2.max())
     for a, b in zip(got2, got):
-        assert float((a - b).abs().max()) <= 1e-5 * max(float(b.abs().max()), 1.0), float((a - b).abs().max())
+        assert float((a - b).abs().max()) <= 1e-4 * max(float(b.abs().max()), 1.0), float((a - b).abs().max())
     err = (dz.float() - dz_ref.float()).abs()
     # one bf16 ulp of the element, or of the intermediate dx spread over its row (small |dz| next to large ones)
     assert bool((err <= 2 ** -7 * dz_ref.float().abs() + 2e-3 * float(dz_ref.float().abs().max())).all()), float(err.max())
