@@ -12,7 +12,9 @@ What changes from step to step and is NOT frozen into the graph:
     node; the LR schedule, the tau schedule (momentum.py:76-87) and the step counters keep running on the host exactly as in the
     eager loop (base.py:1250-1276 order: optimiser step, then EMA with the CURRENT tau, then the tau update);
   * which parameters receive a gradient (the prototypes are frozen while `epoch < freeze_last_layer`, dino.py:367-376) and the
-    channel mix / crop sizes of the batch: part of the signature -- a new signature captures a new graph (kept, keyed).
+    channel mix / crop sizes of the batch: part of the signature -- a new signature captures a new graph (kept, keyed; going back
+    to an earlier signature replays its graph).  Meant for fixed-channel data: with a new channel mix every step every step
+    would capture.
 
 Same kernels, same order, same results as the eager step (tests/test_model_gpu.py::test_graphed_train_step_matches_eager).
 Single process only: the gradient collectives of the data-parallel path are issued from Python hooks and stay eager.
@@ -43,6 +45,7 @@ class GraphedTrainStep:
         self.extra_host = torch.zeros(2, dtype=torch.float32).pin_memory()   # [tau, teacher temperature]
         self.extra_dev = torch.zeros(2, dtype=torch.float32, device=self.device)
         self.graphs: Dict[Tuple, Dict[str, Any]] = {}
+        self._current = None   # signature of the graph whose slot table / active parameters the DeviceHyper holds
         self._entered = False
 
     # ------------------------------------------------------------------------------------------
@@ -57,7 +60,8 @@ class GraphedTrainStep:
     def close(self):
         """Back to the eager loop: step counters written back, device scalars detached."""
         if self._entered:
-            self.hyper.commit(self.trainer.optimizer)
+            self.hyper.switch(self.trainer.optimizer, [], [])
+            self._current = None
             self.trainer.optimizer.device_hyper = None
             self.model.momentum_updater.tau_dev = None
             self.model.dino_loss_func.temp_dev = None
@@ -164,9 +168,10 @@ class GraphedTrainStep:
         key = self._signature(batch, frozen)
         g = self.graphs.get(key)
         if g is None:
-            if self._entered and self.graphs:
-                # another set of active parameters / another batch shape: the step counters go back to the optimizer first
-                self.hyper.commit(tr.optimizer)
+            # another set of active parameters / another batch shape: the step counters go back to the optimizer first and the
+            # capture below builds this graph's own slot table
+            self.hyper.switch(tr.optimizer, [], [])
+            self._current = key
             self._enter()
             g = self._static_batch(batch)
             # warm-up steps run eagerly on a side stream (graph capture requires it; they fill every host-side cache: ragged
@@ -193,7 +198,11 @@ class GraphedTrainStep:
                 self._upload_scalars()
                 g["loss"] = self._body(g["batch"], batch_idx)
             self._restore(snap)   # (host-side counters the captured body touched: none today; cheap and safe)
+            g["hyper_slots"], g["hyper_active"] = list(self.hyper.slots), list(self.hyper.active)
             self.graphs[key] = g
+        elif key != self._current:   # back to a graph captured earlier
+            self.hyper.switch(tr.optimizer, g["hyper_slots"], g["hyper_active"])
+            self._current = key
         self._copy_in(g, batch)
         self._fill_scalars()
         g["graph"].replay()

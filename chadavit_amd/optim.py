@@ -21,38 +21,40 @@ class DeviceHyper:
     """Per-step AdamW scalars in device memory, for launches that are captured once and replayed (chadavit_amd.graphed).
 
     One slot = {lr, 1 - beta1^t, sqrt(1 - beta2^t)} for the parameters of one param group that share a step count (the prototypes
-    frozen during epoch 0 lag behind the rest of their group, exactly as torch.optim.AdamW counts steps per parameter).  While an
+    frozen during epoch 0 lag behind the rest of their group, exactly as torch.optim.AdamW counts steps per parameter); a slot is
+    remembered by one representative parameter, so its step count is always read from the live optimizer state.  While an
     optimizer runs with `device_hyper` set it does NOT advance its per-parameter counters: parameter p is at step
-    `state[p]["step"] + taken`; `advance()` after every (eager or replayed) step, `commit()` to write the counters back."""
+    `state[p]["step"] + taken`; `advance()` after every (eager or replayed) step, `commit()` writes the counters back -- before
+    another captured graph (another set of active parameters) takes over, or when leaving device mode."""
 
     def __init__(self, device, max_slots: int = 16):
         self.host = torch.zeros(3 * max_slots, dtype=torch.float32).pin_memory()
         self.dev = torch.zeros(3 * max_slots, dtype=torch.float32, device=device)
-        self.slots: List[tuple] = []   # (group index, step count of the parameters when this object took over)
-        self.taken = 0                 # optimizer steps taken through this object
-        self.active: List = []         # parameters that were stepped through it
+        self.slots: List[tuple] = []   # (group index, representative parameter)
+        self.taken = 0                 # optimizer steps taken through this object since the last commit
+        self.active: List = []         # parameters that are stepped through it (the current graph's)
 
-    def slot(self, gi: int, p, state) -> torch.Tensor:
-        key = (gi, int(state.get("step", 0)))
-        if key not in self.slots:
+    def slot(self, gi: int, p, state, optimizer_state) -> torch.Tensor:
+        step = int(state.get("step", 0))
+        i = next((k for k, (g, rep) in enumerate(self.slots) if g == gi and int(optimizer_state[rep].get("step", 0)) == step), None)
+        if i is None:
             if 3 * (len(self.slots) + 1) > self.host.numel():
                 raise RuntimeError("DeviceHyper: more (group, step count) classes than slots")
-            self.slots.append(key)
-        if not state.get("dev_active", False):
-            state["dev_active"] = True
+            self.slots.append((gi, p))
+            i = len(self.slots) - 1
+        if not any(q is p for q in self.active):
             self.active.append(p)
-        i = self.slots.index(key)
         return self.dev[3 * i:3 * i + 3]
 
     def fill(self, optimizer) -> None:
         """Host values for the NEXT step (read by the graph's first node, a copy host -> dev)."""
-        for i, (gi, step0) in enumerate(self.slots):
+        import numpy as np
+        for i, (gi, rep) in enumerate(self.slots):
             g = optimizer.param_groups[gi]
             b1, b2 = g["betas"]
-            t = step0 + self.taken + 1
+            t = int(optimizer.state[rep].get("step", 0)) + self.taken + 1
             # the same float32 roundings as the by-value path (ops.adamw_step -> chadavit_adamw_step: bias corrections rounded to
             # float32, then sqrtf in float32), so that a replayed step is bit-identical to an eager one
-            import numpy as np
             self.host[3 * i] = float(g["lr"])
             self.host[3 * i + 1] = float(np.float32(1.0 - b1 ** t))
             self.host[3 * i + 2] = float(np.sqrt(np.float32(1.0 - b2 ** t)))
@@ -61,12 +63,16 @@ class DeviceHyper:
         self.taken += 1
 
     def commit(self, optimizer) -> None:
-        """Write the step counters back (leaving device mode, or before a re-capture with another set of active parameters)."""
+        """Write the step counters of the active parameters back (`taken` steps each) and start counting from zero again."""
         for p in self.active:
             st = optimizer.state[p]
             st["step"] = int(st.get("step", 0)) + self.taken
-            st["dev_active"] = False
-        self.active, self.slots, self.taken = [], [], 0
+        self.taken = 0
+
+    def switch(self, optimizer, slots: List[tuple], active: List) -> None:
+        """Another captured graph takes over: counters written back, then ITS slot table and active set."""
+        self.commit(optimizer)
+        self.slots, self.active = list(slots), list(active)
 
 
 class FusedAdamW(torch.optim.Optimizer):
@@ -119,7 +125,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 if dh is None:
                     st["step"] = st.get("step", 0) + 1
                 else:
-                    hyper = dh.slot(gi, p, st)
+                    hyper = dh.slot(gi, p, st, self.state)
                 loc = self._where.get(id(p))
                 if loc is None:  # parameter outside the flat slabs (e.g. online classifier if it ever gets a gradient)
                     if "exp_avg" not in st:

@@ -895,10 +895,10 @@ def test_graphed_train_step_matches_eager(n_small):
     from chadavit_amd.methods.dino import DINO
     from chadavit_amd.trainer import Trainer
     dev = _dev()
-    nch = [1, 1, 2, 1]
     sizes = [224, 224] + [96] * n_small
     batches = []
     for s_ in range(6):
+        nch = [1, 1, 2, 1] if s_ % 2 == 0 else [2, 1, 1, 1]   # two channel mixes alternate: each has its own graph, revisited
         crops, labels, ncl = one_channel_collate_fn(P.make_images(nch, sizes, seed=300 + s_))
         crops = crops if isinstance(crops, list) else [crops]
         batches.append(([c.to(dev) for c in crops], labels.to(dev), ncl if isinstance(ncl[0], list) else [ncl]))
@@ -916,7 +916,7 @@ def test_graphed_train_step_matches_eager(n_small):
             tr.current_epoch = i // 3
             losses.append(float(step(b, i % 3).item()))
         if mode == "graph":
-            assert len(step.graphs) == 2   # frozen / unfrozen prototypes
+            assert len(step.graphs) == 4   # (two channel mixes) x (frozen / unfrozen prototypes)
             step.close()
         torch.cuda.synchronize()
         opt = tr.optimizer
