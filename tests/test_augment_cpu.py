@@ -160,3 +160,41 @@ def test_idrcell_reader(tmp_path):
     ds2 = IDRCell100K(root_dir=str(root), train=True, transform=lambda image: seen.setdefault("shape", image.shape) and {"image": image})
     out, _ = ds2[2]
     assert seen["shape"] == (22, 24, 5)
+
+
+def test_device_prefetcher_plumbing_without_a_gpu():
+    """DevicePrefetcher's host side (reader pool, bounded queue, ordering, error hand-over, early exit) with a stand-in pipeline on the
+    CPU: batches arrive in sampler order, each built from exactly the planes of its indices; a reader error reaches the consumer; a
+    consumer that stops early does not leave the producer thread behind."""
+    import threading
+    from chadavit_amd.data.loader import DevicePrefetcher, InMemoryPlanes
+
+    class FakePipe:
+        device = torch.device("cpu")
+
+        def __call__(self, planes, labels=None):
+            x = torch.stack([torch.from_numpy(p).sum() for p in planes])
+            return [x, x + 1], torch.as_tensor(labels if labels is not None else [-1] * len(planes)), [[p.shape[0] for p in planes]] * 2
+
+    rs = np.random.RandomState(0)
+    ds = InMemoryPlanes([rs.rand(1 + i % 3, 4, 5).astype(np.float32) for i in range(12)])
+    batches = [[0, 5, 7], [1, 2, 3], [11, 4, 6], [8, 9, 10]]
+    got = list(DevicePrefetcher(ds, batches, FakePipe(), depth=2, workers=3, labels=list(range(100, 112))))
+    assert len(got) == 4
+    for idx, (crops, labels, ncl) in zip(batches, got):
+        np.testing.assert_allclose(crops[0].numpy(), [ds.planes[i].sum() for i in idx], rtol=1e-6)
+        assert labels.tolist() == [100 + i for i in idx] and ncl[0] == [ds.planes[i].shape[0] for i in idx]
+
+    class Broken(InMemoryPlanes):
+        def read_planes(self, index):
+            if index == 3:
+                raise OSError("unreadable channel file")
+            return super().read_planes(index)
+
+    with pytest.raises(OSError, match="unreadable channel file"):
+        list(DevicePrefetcher(Broken(ds.planes), batches, FakePipe(), depth=1, workers=2))
+    n0 = threading.active_count()
+    it = iter(DevicePrefetcher(ds, batches * 50, FakePipe(), depth=1, workers=2))
+    next(it); next(it)
+    it.close()   # generator exit: the producer is told to stop and joined
+    assert threading.active_count() <= n0
