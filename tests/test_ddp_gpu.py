@@ -224,3 +224,33 @@ def test_disk_to_training_step_on_two_ranks(tmp_path):
     assert a["w"] == b["w"] and a["wt"] == b["wt"] and abs(a["center"] - b["center"]) <= 1e-6 * abs(a["center"]) + 1e-9
     # sync_dist: both ranks read the same mean of their last local losses
     assert abs(a["logged"] - b["logged"]) < 1e-9 and abs(a["logged"] - 0.5 * (a["losses"][-1] + b["losses"][-1])) < 1e-4
+
+
+@pytest.mark.timeout(1200)
+def test_bench_contract_single_gpu_with_all_legs():
+    """`python bench.py` as the driver runs it at N = 1 (smaller batch, no CPU baseline): ONE JSON line with the contract's keys, the
+    roofline object, the full-width leg, the cfg3 / cfg5 / cfg1 (eager and hipGraph) legs without an error entry, and the data-path
+    leg.  Guards the round-end bench run against a leg that raises."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "32", "--no-cpu-baseline",
+                        "--data", "pipeline"], cwd=ROOT, capture_output=True, text=True, timeout=1100)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline"):
+        assert k in out, k
+    assert out["n_gpus"] == 1 and out["steps"] == 2 and out["value"] > 0 and out["dtype"] == "bf16" and out["vs_baseline"] is None
+    rf = out["roofline"]
+    assert rf["bound"] in ("mfma", "hbm") and 0 < rf["frac"] < 1 and rf["avg_us"] > 0 and rf["kernel"]
+    cfg = out["config"]
+    assert cfg["images_per_s_with_full_width_last_block"] > 0 and "workload" in cfg
+    legs = cfg["other_workloads"]
+    assert set(legs) == {"cfg3", "cfg5", "cfg1", "cfg1-graph"}
+    for name, leg in legs.items():
+        assert "error" not in leg, (name, leg)
+        assert leg["images_per_s"] > 0 and leg["ms_per_step"] > 0
+    assert legs["cfg1-graph"]["launch"].startswith("one hipGraph") and legs["cfg1"]["launch"] == "eager"   # (no timing assertions here)
+    dp = cfg["data_path"]
+    assert "error" not in dp and dp["step_fed_by_pipeline_images_per_s"] > 0 and dp["decode_images_per_s_per_reader_thread"] > 0
