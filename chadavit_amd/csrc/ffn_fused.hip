@@ -167,6 +167,13 @@ __device__ __forceinline__ unsigned relu_mask8(u32x4 x) {
 // machinery -- X fragments = dz, "W1" records = W2^T chunk (GEMM1 gives dH = dz W2 for the chunk, no bias), the ReLU is replaced
 // by the mask `rbits` recorded by the forward (dpre = dH where the forward's hidden value was > 0), "W2" records = W1^T chunk
 // (GEMM2 accumulates dx1 += dpre W1).
+__device__ __forceinline__ void ffn_issue(BufRsrc wrs, unsigned blk_bytes, bf16_t* __restrict__ dst, int w, int l) {
+#pragma unroll
+  for (int i = 0; i < BLK_FRAGS / NWV; ++i) {   // record f of a block goes to wave f % NWV
+    const int f = w + NWV * i;
+    lds_dma16(wrs, dst + f * FRAG_ELEMS, l * 16, blk_bytes + f * (FRAG_ELEMS * 2));
+  }
+}
 template <int RT, bool WRITE_H, bool DO_G1, bool DO_G2, bool GATHER, bool DO_P = false, int MODE = 0>
 __device__ __forceinline__ void ffn_core(BufRsrc wrs, unsigned blk_bytes, bf16_t* __restrict__ dst,
                                          const bf16_t* __restrict__ st, const float* __restrict__ sb1,
@@ -379,6 +386,16 @@ __global__ __launch_bounds__(64 * NWV, (RT * NWV <= 8 ? 2 : 1)) void ffn_fwd_ker
   for (int i = 0; i < BLK_FRAGS / NWV; ++i) lds_dma16(wrs, smem + (w + NWV * i) * FRAG_ELEMS, l * 16, (w + NWV * i) * (FRAG_ELEMS * 2));
   if constexpr (MODE != 2)
     for (int i = tid; i < FF / 4; i += 64 * NWV) reinterpret_cast<f32x4*>(sB1)[i] = reinterpret_cast<const f32x4*>(b1)[i];
+  // Small per-column vectors are read from LDS wherever their use sits between STORES: loads and stores share the one vmcnt
+  // counter, so "load bias, wait, add, store, load the next bias, wait ..." makes every wait sit out the store before it -- a
+  // store round trip (microseconds while the write queues are busy) per 16-byte piece, ~70 of them per 128-row block.  bo / gamma1 /
+  // beta1 of the prologue's LayerNorm go into the H slab (idle until the FFN loop), b2 behind the tail's gamma / beta in the bias
+  // slab (b1 is dead by then; no DMA is in flight there, so hipcc adds no vmcnt guard to those LDS reads).
+  constexpr bool PRO_LDS = PRO && WRITE_H;
+  if constexpr (PRO_LDS) {
+    float* const sP = reinterpret_cast<float*>(sH);
+    for (int i = tid; i < FD; i += 64 * NWV) { sP[i] = pro.bo[i]; sP[FD + i] = pro.g1[i]; sP[2 * FD + i] = pro.be1[i]; }
+  }
 
   bf16x8 xf[RT][KS1];
   int mrow[RT];
@@ -416,6 +433,7 @@ __global__ __launch_bounds__(64 * NWV, (RT * NWV <= 8 ? 2 : 1)) void ffn_fwd_ker
   bf16_t* const smem_o = smem + opq;
   float* const sB1_o = sB1 + opq;
   bf16_t* const sH_o = sH + opq;
+  const float* const sP_o = reinterpret_cast<const float*>(sH_o);
   if constexpr (PRO) {
     // stream blocks 0..2 = Wo; the ring continues into the FFN blocks (stream block 3 + k), so the steps below already issue
     // FFN block 0 (and 1 with three stages)
@@ -447,8 +465,14 @@ __global__ __launch_bounds__(64 * NWV, (RT * NWV <= 8 ? 2 : 1)) void ffn_fwd_ker
 #pragma unroll
       for (int p = 0; p < NT2 / 2; ++p) {
         const int col = 32 * p + 8 * g;
-        f32x4 v0 = oacc[rt][2 * p] + *reinterpret_cast<const f32x4*>(pro.bo + col);
-        f32x4 v1 = oacc[rt][2 * p + 1] + *reinterpret_cast<const f32x4*>(pro.bo + col + 4);
+        f32x4 v0, v1;
+        if constexpr (PRO_LDS) {
+          v0 = oacc[rt][2 * p] + *reinterpret_cast<const f32x4*>(sP_o + col);
+          v1 = oacc[rt][2 * p + 1] + *reinterpret_cast<const f32x4*>(sP_o + col + 4);
+        } else {
+          v0 = oacc[rt][2 * p] + *reinterpret_cast<const f32x4*>(pro.bo + col);
+          v1 = oacc[rt][2 * p + 1] + *reinterpret_cast<const f32x4*>(pro.bo + col + 4);
+        }
         bf16x8 o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -473,8 +497,14 @@ __global__ __launch_bounds__(64 * NWV, (RT * NWV <= 8 ? 2 : 1)) void ffn_fwd_ker
 #pragma unroll
       for (int p = 0; p < NT2 / 2; ++p) {
         const int col = 32 * p + 8 * g;
-        const f32x4 g0 = *reinterpret_cast<const f32x4*>(pro.g1 + col), g1v = *reinterpret_cast<const f32x4*>(pro.g1 + col + 4);
-        const f32x4 e0 = *reinterpret_cast<const f32x4*>(pro.be1 + col), e1 = *reinterpret_cast<const f32x4*>(pro.be1 + col + 4);
+        f32x4 g0, g1v, e0, e1;
+        if constexpr (PRO_LDS) {
+          g0 = *reinterpret_cast<const f32x4*>(sP_o + FD + col); g1v = *reinterpret_cast<const f32x4*>(sP_o + FD + col + 4);
+          e0 = *reinterpret_cast<const f32x4*>(sP_o + 2 * FD + col); e1 = *reinterpret_cast<const f32x4*>(sP_o + 2 * FD + col + 4);
+        } else {
+          g0 = *reinterpret_cast<const f32x4*>(pro.g1 + col); g1v = *reinterpret_cast<const f32x4*>(pro.g1 + col + 4);
+          e0 = *reinterpret_cast<const f32x4*>(pro.be1 + col); e1 = *reinterpret_cast<const f32x4*>(pro.be1 + col + 4);
+        }
         bf16x8 o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -521,6 +551,9 @@ __global__ __launch_bounds__(64 * NWV, (RT * NWV <= 8 ? 2 : 1)) void ffn_fwd_ker
     // NC is even: iterations come in (odd, even) pairs
     for (int k = 1; k < NC; k += 2) {
       {  // odd k
+        // (vmcnt(0), not "all but the H stores of the even iteration before": tried -- stores issued behind the DMA, vmcnt(NPEND)
+        // here -- and WRONG: a store can retire before an older load, so a count that relies on younger stores still being in
+        // flight lets the barrier pass with DMA pieces missing; test_ffn_bwd_dx_from_relu_bits caught it: 0.16 % of dx1 off)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         mask_pre(k);
         ffn_core<RT, true, true, true, true, false, MODE>(wrs, blk(k + 1), smem_o + ((k + 1 + J3) & 1) * STAGE, smem_o + ((k + J3) & 1) * STAGE, sB1_o,
@@ -544,16 +577,20 @@ __global__ __launch_bounds__(64 * NWV, (RT * NWV <= 8 ? 2 : 1)) void ffn_fwd_ker
   // ---- epilogue: + b2 + residual (+ LayerNorm tail), 16-byte stores straight from the accumulators
   constexpr int NP = NT2 / 2;
   constexpr float invD = 1.0f / FD;
-  float* const sLn = sB1;  // the bias slab is dead now: gamma / beta of the tail are staged there ([ga | ba | gb | bb], FD each)
-  if (ln.mode) {
+  float* const sLn = sB1;  // the bias slab is dead now: gamma / beta of the tail are staged there ([ga | ba | gb | bb], FD each), then b2
+  {
     __syncthreads();
     for (int i = tid; i < FD; i += 64 * NWV) {
-      sLn[i] = ln.ga[i];
-      sLn[FD + i] = ln.ba[i];
-      if (ln.mode == 2) { sLn[2 * FD + i] = ln.gb[i]; sLn[3 * FD + i] = ln.bb[i]; }
+      if (ln.mode) {
+        sLn[i] = ln.ga[i];
+        sLn[FD + i] = ln.ba[i];
+        if (ln.mode == 2) { sLn[2 * FD + i] = ln.gb[i]; sLn[3 * FD + i] = ln.bb[i]; }
+      }
+      if constexpr (MODE != 2) sLn[4 * FD + i] = b2[i];
     }
     __syncthreads();
   }
+  const bool resid_is_x = !PRO && resid == X && ldr == ldx;   // (uniform)
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     const int m = m0 + rt * 16 + li;
@@ -565,12 +602,12 @@ __global__ __launch_bounds__(64 * NWV, (RT * NWV <= 8 ? 2 : 1)) void ffn_fwd_ker
       const int col = 32 * p + 8 * g;
       f32x4 v0 = oacc[rt][2 * p], v1 = oacc[rt][2 * p + 1];
       if constexpr (MODE != 2) {
-        v0 += *reinterpret_cast<const f32x4*>(b2 + col);
-        v1 += *reinterpret_cast<const f32x4*>(b2 + col + 4);
+        v0 += *reinterpret_cast<const f32x4*>(sLn + 4 * FD + col);
+        v1 += *reinterpret_cast<const f32x4*>(sLn + 4 * FD + col + 4);
       }
-      if constexpr (PRO) {  // the residual is x1 = the X fragment of this pair: same rows, same 8 columns, already in registers
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { v0[r] += (float)xf[rt][p][r]; v1[r] += (float)xf[rt][p][4 + r]; }
+      if (PRO || resid_is_x) {  // the residual is the X fragment of this pair: same rows, same 8 columns, already in registers
+#pragma unroll                   // (PRO: x1; otherwise whenever the caller passes resid == X -- a load here would sit between the stores
+        for (int r = 0; r < 4; ++r) { v0[r] += (float)xf[rt][p][r]; v1[r] += (float)xf[rt][p][4 + r]; }   // and drain them one by one)
       } else if (resid) {
         const bf16x8 rv = *reinterpret_cast<const bf16x8*>(resid + (size_t)mr * ldr + col);
 #pragma unroll
@@ -667,6 +704,15 @@ __global__ __launch_bounds__(64 * NWV, (RT * NWV <= 8 ? 2 : 1)) void ffn_fwd_ker
           ffn_core<RT, WRITE_H, false, false, false, true, MODE>(wrs, qblk(q + LA), smem_o + ((q + LA) % NST) * STAGE, smem_o + (q % NST) * STAGE,
                                                            sB1_o, sH_o, q + LA < 3 * NPB, j, w, l, xf, oacc, hb, pend, rbits);
         }
+        // the slice's bias: ALL of it requested here, before the slice's first store.  Fetched inside the store loop, every piece's
+        // wait sat out the store in front of it (one vmcnt counter for loads and stores: 36 store round trips per block); read
+        // from LDS, hipcc guards each read against the ring's DMA in flight with a vmcnt wait that does the same.  (Earlier than
+        // here there are no registers for it.)
+        f32x4 qb[NT2];
+#pragma unroll
+        for (int n = 0; n < NT2; ++n) qb[n] = *reinterpret_cast<const f32x4*>(pro.bqkv + FD * c + 32 * (n >> 1) + 8 * g + 4 * (n & 1));
+#pragma unroll
+        for (int n = 0; n < NT2; ++n) asm volatile("" ::"v"(qb[n]));   // (one wait, here)
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
           const int m = m0 + rt * 16 + li;
@@ -674,8 +720,8 @@ __global__ __launch_bounds__(64 * NWV, (RT * NWV <= 8 ? 2 : 1)) void ffn_fwd_ker
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
               const int col = FD * c + 32 * p + 8 * g;
-              const f32x4 v0 = oacc[rt][2 * p] + *reinterpret_cast<const f32x4*>(pro.bqkv + col);
-              const f32x4 v1 = oacc[rt][2 * p + 1] + *reinterpret_cast<const f32x4*>(pro.bqkv + col + 4);
+              const f32x4 v0 = oacc[rt][2 * p] + qb[2 * p];
+              const f32x4 v1 = oacc[rt][2 * p + 1] + qb[2 * p + 1];
               bf16x8 o;
 #pragma unroll
               for (int r = 0; r < 4; ++r) { o[r] = (bf16_t)v0[r]; o[4 + r] = (bf16_t)v1[r]; }

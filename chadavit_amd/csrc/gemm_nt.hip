@@ -58,16 +58,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 
 // Epilogue for 8 consecutive output columns n..n+7 of row m (v0 = cols n..n+3, v1 = n+4..n+7).
 template <int EPI, bool OUT_F32>
-__device__ __forceinline__ void epi_store(const NtArgs& a, f32x4 v0, f32x4 v1, int m, int n, int N) {
-  const float* __restrict__ bias = a.bias;
-  const bf16_t* __restrict__ aux = a.aux;
+__device__ __forceinline__ void epi_store(const NtArgs& a, f32x4 v0, f32x4 v1, f32x4 b0, f32x4 b1, bf16x8 rr, int m, int n, int N) {
   bf16_t* __restrict__ aux_out = a.aux_out;
   const int ldo = a.ldo, ldaux = a.ldaux;
   void* Out = a.Out;
-  if (bias) {
-    v0 += *reinterpret_cast<const f32x4*>(bias + n);
-    v1 += *reinterpret_cast<const f32x4*>(bias + n + 4);
-  }
+  v0 += b0;   // (the caller fetched the bias of its columns before its first store: a load between two stores waits for the
+  v1 += b1;   //  first one as well -- loads and stores share the one vmcnt counter)
   int orow = m;
   if constexpr (EPI == EPI_RELU) {
 #pragma unroll
@@ -79,19 +75,16 @@ __device__ __forceinline__ void epi_store(const NtArgs& a, f32x4 v0, f32x4 v1, i
     *reinterpret_cast<bf16x8*>(aux_out + (size_t)m * ldaux + n) = pre;
 #pragma unroll
     for (int r = 0; r < 4; ++r) { v0[r] = gelu_erf(v0[r]); v1[r] = gelu_erf(v1[r]); }
-  } else if constexpr (EPI == EPI_RESID) {
-    const bf16x8 rr = *reinterpret_cast<const bf16x8*>(aux + (size_t)m * ldaux + n);
+  } else if constexpr (EPI == EPI_RESID) {   // (rr: the aux piece, fetched by the caller before its first store)
 #pragma unroll
     for (int r = 0; r < 4; ++r) { v0[r] += (float)rr[r]; v1[r] += (float)rr[4 + r]; }
-  } else if constexpr (EPI == EPI_RELUMASK) {
-    const bf16x8 rr = *reinterpret_cast<const bf16x8*>(aux + (size_t)m * ldaux + n);
+  } else if constexpr (EPI == EPI_RELUMASK) {   // (rr: the aux piece, fetched by the caller before its first store)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       v0[r] = ((float)rr[r] > 0.f) ? v0[r] : 0.f;
       v1[r] = ((float)rr[4 + r] > 0.f) ? v1[r] : 0.f;
     }
-  } else if constexpr (EPI == EPI_GELUBWD) {
-    const bf16x8 rr = *reinterpret_cast<const bf16x8*>(aux + (size_t)m * ldaux + n);
+  } else if constexpr (EPI == EPI_GELUBWD) {   // (rr: the aux piece, fetched by the caller before its first store)
 #pragma unroll
     for (int r = 0; r < 4; ++r) { v0[r] *= gelu_erf_grad((float)rr[r]); v1[r] *= gelu_erf_grad((float)rr[4 + r]); }
   } else if constexpr (EPI == EPI_TOKEN) {
@@ -227,6 +220,32 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NtArgs a) {
   static_assert(4 * 16 * STG * 4 <= (BM + BN) * LDK * 2, "epilogue staging must fit the tile buffers");
   float* stage = reinterpret_cast<float*>(smem) + w * 16 * STG;
   const int g = l >> 4, li = l & 15;
+  f32x4 bb[CPL][2];   // the bias of the lane's column chunks (the same in every 16-row pass)
+#pragma unroll
+  for (int cc = 0; cc < CPL; ++cc) {
+    const int n = n0 + wn * TN + ((l + 64 * cc) % CH) * 8;
+    bb[cc][0] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    bb[cc][1] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + n + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int cc = 0; cc < CPL; ++cc) asm volatile("" ::"v"(bb[cc][0]), "v"(bb[cc][1]));   // waited for HERE, once, not inside every row guard below
+  // ... and the residual / mask / pre-activation pieces of the whole tile, for the same reason (rows past M: row M - 1, not stored)
+  constexpr bool HAS_AUX = EPI == EPI_RESID || EPI == EPI_RELUMASK || EPI == EPI_GELUBWD;
+  bf16x8 ax[HAS_AUX ? MB : 1][HAS_AUX ? CPL : 1];
+  if constexpr (HAS_AUX) {
+#pragma unroll
+    for (int j = 0; j < MB; ++j)
+#pragma unroll
+      for (int cc = 0; cc < CPL; ++cc) {
+        const int id = l + 64 * cc;
+        const int m = min(m0 + wm * TM + j * 16 + id / CH, M - 1);
+        ax[j][cc] = *reinterpret_cast<const bf16x8*>(a.aux + (size_t)m * a.ldaux + n0 + wn * TN + (id % CH) * 8);
+      }
+#pragma unroll
+    for (int j = 0; j < MB; ++j)
+#pragma unroll
+      for (int cc = 0; cc < CPL; ++cc) asm volatile("" ::"v"(ax[j][cc]));
+  }
 #pragma unroll
   for (int j = 0; j < MB; ++j) {
 #pragma unroll
@@ -238,7 +257,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NtArgs a) {
       const int n = n0 + wn * TN + ch * 8;
       f32x4 v0 = *reinterpret_cast<const f32x4*>(stage + row * STG + ch * 8);
       f32x4 v1 = *reinterpret_cast<const f32x4*>(stage + row * STG + ch * 8 + 4);
-      if (m < M) epi_store<EPI, OUT_F32>(a, v0, v1, m, n, N);
+      if (m < M) epi_store<EPI, OUT_F32>(a, v0, v1, bb[cc][0], bb[cc][1], ax[HAS_AUX ? j : 0][HAS_AUX ? cc : 0], m, n, N);
     }
   }
 }
@@ -352,6 +371,32 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(NtArgs a) {
   constexpr int STG = TN + 4, CH = TN / 8, CPL = 16 * CH / 64;
   static_assert(4 * 16 * STG * 4 <= 2 * STAGE * 2, "epilogue staging must fit the stage buffers");
   float* stage = reinterpret_cast<float*>(smem) + w * 16 * STG;
+  f32x4 bb[CPL][2];   // the bias of the lane's column chunks (the same in every 16-row pass)
+#pragma unroll
+  for (int cc = 0; cc < CPL; ++cc) {
+    const int n = n0 + wn * TN + ((l + 64 * cc) % CH) * 8;
+    bb[cc][0] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    bb[cc][1] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + n + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int cc = 0; cc < CPL; ++cc) asm volatile("" ::"v"(bb[cc][0]), "v"(bb[cc][1]));   // waited for HERE, once, not inside every row guard below
+  // ... and the residual / mask / pre-activation pieces of the whole tile, for the same reason (rows past M: row M - 1, not stored)
+  constexpr bool HAS_AUX = EPI == EPI_RESID || EPI == EPI_RELUMASK || EPI == EPI_GELUBWD;
+  bf16x8 ax[HAS_AUX ? MB : 1][HAS_AUX ? CPL : 1];
+  if constexpr (HAS_AUX) {
+#pragma unroll
+    for (int j = 0; j < MB; ++j)
+#pragma unroll
+      for (int cc = 0; cc < CPL; ++cc) {
+        const int id = l + 64 * cc;
+        const int m = min(m0 + wm * TM + j * 16 + id / CH, M - 1);
+        ax[j][cc] = *reinterpret_cast<const bf16x8*>(a.aux + (size_t)m * a.ldaux + n0 + wn * TN + (id % CH) * 8);
+      }
+#pragma unroll
+    for (int j = 0; j < MB; ++j)
+#pragma unroll
+      for (int cc = 0; cc < CPL; ++cc) asm volatile("" ::"v"(ax[j][cc]));
+  }
 #pragma unroll
   for (int j = 0; j < MB; ++j) {
 #pragma unroll
@@ -363,7 +408,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(NtArgs a) {
       const int n = n0 + wn * TN + ch * 8;
       const f32x4 v0 = *reinterpret_cast<const f32x4*>(stage + row * STG + ch * 8);
       const f32x4 v1 = *reinterpret_cast<const f32x4*>(stage + row * STG + ch * 8 + 4);
-      if (m < M) epi_store<EPI, OUT_F32>(a, v0, v1, m, n, N);
+      if (m < M) epi_store<EPI, OUT_F32>(a, v0, v1, bb[cc][0], bb[cc][1], ax[HAS_AUX ? j : 0][HAS_AUX ? cc : 0], m, n, N);
     }
   }
 }
