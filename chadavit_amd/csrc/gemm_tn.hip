@@ -284,13 +284,39 @@ extern "C" int chadavit_gemm_tn(const chada_bf16* A_, int lda, const chada_bf16*
   // three times instead of nine
   static const bool big = getenv("CHADA_TN_NO192") == nullptr;
   if (big && bi == 64 && bj == 192 && I % 192 == 0 && I >= 384) bi = 192;
+  // wide outputs (Base: 2304 x 768, 768 x 768): there the kernel is bound by the CU's vector-memory path (LDS-DMA, ~58 B/clk), not by
+  // HBM, and a 192 x 192 tile stages 25 % fewer bytes per FLOP than 128 x 192
+  static const int wide = getenv("CHADA_TN_WIDE") ? atoi(getenv("CHADA_TN_WIDE")) : 1;
+  if (wide && I % 192 == 0 && J % 192 == 0 && (long long)I * J >= 768ll * 768) { bi = 192; bj = 192; }
   const int tiles = (I / bi) * (J / bj);
-  int splits = (512 + tiles - 1) / tiles;  // two resident blocks per CU, one wave of blocks: more (or fewer) measured slower
-  const int max_by_t = (T + 255) / 256;  // at least 256 rows per split
-  if (splits > max_by_t) splits = max_by_t;
+  // T-splits.  tn_decode gives split s to XCD s % 8 (all tiles of a split share one L2), each XCD has 32 CUs x 2 resident blocks = 64
+  // slots, and a block's time goes with its rows: with n splits per XCD the launch takes ceil(tiles n / 64) rounds of T / (8 n) rows.
+  // The old rule (512 / tiles splits, any number) left XCDs with 66 or 72 blocks for 64 slots -- a second round for a handful of
+  // blocks: 2304 x 768 ran at 620 TFLOP/s beside 2048 x 768 at 890 on the same tile.  Now: the n with the lowest modelled time,
+  // the partial slabs (8 n I J floats written and read once) priced in.
   const long long per = (long long)I * J + I;
-  if (splits > workspace_floats / per) splits = (int)(workspace_floats / per);
-  if (splits < 1) return 1;
+  const int max_by_t = (T + 255) / 256;  // at least 256 rows per split
+  const long long max_by_ws = workspace_floats / per;
+  if (max_by_ws < 1) return 1;
+  int splits;
+  {
+    const double t_full = fmax(2.0 * T * I * J / 0.95e15, 2.0 * T * (double)(I + J) / 4.6e12);   // seconds at full occupancy
+    double best = 1e30;
+    int best_n = 0;
+    for (int n = 1; n <= 64; ++n) {
+      if (8 * n > max_by_t || 8 * n > max_by_ws) break;
+      const int rounds = (tiles * n + 63) / 64;
+      const double t = t_full * (64.0 * rounds) / ((double)tiles * n) + 8.0 * n * (double)I * J * 8.0 / 4.0e12;
+      if (t < best) { best = t; best_n = n; }
+    }
+    splits = best_n ? 8 * best_n : (int)((max_by_ws < max_by_t ? max_by_ws : max_by_t) < 1 ? 1 : (max_by_ws < max_by_t ? max_by_ws : max_by_t));
+  }
+  static const bool old_rule = getenv("CHADA_TN_OLD_SPLITS") != nullptr;   // (same-box A/B against the round-2 rule)
+  if (old_rule) {
+    splits = (512 + tiles - 1) / tiles;
+    if (splits > max_by_t) splits = max_by_t;
+    if (splits > max_by_ws) splits = (int)max_by_ws;
+  }
   int tchunk = (T + splits - 1) / splits;
   tchunk = (tchunk + 63) / 64 * 64;
   splits = (T + tchunk - 1) / tchunk;
