@@ -612,7 +612,11 @@ int launch_nt(const NtArgs& a, hipStream_t s) {
 #define NT_LAUNCH(BNV)                                                                                               \
   if (longk) hipLaunchKernelGGL((gemm_nt_glds_kernel<BM, BNV, EPI, OUT_F32>), dim3(tm * (a.N / BNV)), dim3(256), 0, s, a); \
   else hipLaunchKernelGGL((gemm_nt_kernel<BM, BNV, EPI, OUT_F32>), dim3(tm * (a.N / BNV)), dim3(256), 0, s, a);
-  if (a.N == 384 && longk) {  // two 192-wide tiles per row panel instead of three 128-wide ones
+  static const int wide192 = getenv("CHADA_NT_BN192") ? atoi(getenv("CHADA_NT_BN192")) : 1;
+  if ((a.N == 384 || (wide192 && a.N % 192 == 0 && a.N >= 768)) && longk) {
+    // N = 384: two 192-wide tiles per row panel instead of three 128-wide ones.  N = 768, 2304 (Base): a 128 x 128 tile stages
+    // 64 B/clk of operands at the matrix pipe's pace -- more than the CU's vector-memory path delivers (~58 B/clk through LDS-DMA);
+    // 128 x 192 needs 53
     NT_LAUNCH(192)
   } else if (a.N % 128 == 0) {
     NT_LAUNCH(128)
