@@ -157,7 +157,9 @@ class ChAdaViT(nn.Module):
     def _workspaces(self, dev):
         D = self.embed_dim
         if self._tn_ws is None or self._tn_ws.device != dev:
-            self._tn_ws = torch.empty(max(24 * 1024 * 1024, 4 * (FFN_DIM * D + FFN_DIM)), device=dev, dtype=torch.float32)
+            # partial slabs of the weight-gradient GEMM: room for 32 T-splits of the widest gradient (dW_qkv: 3D x D) -- chadavit_gemm_tn picks
+            # the split count that fills whole rounds of every XCD and is clamped by what fits here (Base: 57 M floats)
+            self._tn_ws = torch.empty(max(24 * 1024 * 1024, 32 * (3 * D * D + 3 * D), 4 * (FFN_DIM * D + FFN_DIM)), device=dev, dtype=torch.float32)
             self._ln_ws = ops.layernorm_bwd_workspace(D, dev)
         return self._tn_ws, self._ln_ws
 

@@ -165,7 +165,9 @@ class _HeadFn(torch.autograd.Function):
         if head._tn_ws is None or head._tn_ws.device != dev:
             P, K = flat.shapes["last_layer.weight_v"]
             hid = flat.shapes["mlp.2.weight"][0]
-            head._tn_ws = torch.empty(2 * max(P * K + P, hid * hid + hid), device=dev, dtype=torch.float32)
+            # eight T-splits of the widest gradient: one per XCD (chadavit_gemm_tn sends split s to XCD s % 8; with room for two, the
+            # prototype layer's gradient ran on two XCDs)
+            head._tn_ws = torch.empty(8 * max(P * K + P, hid * hid + hid), device=dev, dtype=torch.float32)
         ws = head._tn_ws
         w0 = head.mlp[0].weight
         acc = w0.grad is not None and w0.grad.data_ptr() == G("mlp.0.weight").data_ptr()

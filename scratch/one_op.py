@@ -54,5 +54,15 @@ elif name in ("attn_fwd", "attn_bwd"):
     do = torch.randn((rb.T, 192), device=dev).to(bf); dq = torch.empty_like(qkv); dl = torch.empty((2, rb.T), device=dev)
     fn = (lambda: ops.attn_fwd(qkv, rb.cu_seqlens, rb.work, 2, out=o, lse=lse)) if name == "attn_fwd" else \
          (lambda: ops.attn_bwd(qkv, o, do, lse, rb.cu_seqlens, rb.work, 2, dqkv=dq, delta=dl))
+elif name in ("attn_fwd_base", "attn_bwd_base", "attn_fwd_small", "attn_bwd_small"):
+    # Base: 64 images x 10 channels (1961 tokens), 2 heads of 384; Small: 120 images x 10 channels, 2 heads of 192
+    base = name.endswith("base")
+    D = 768 if base else 384
+    rb = RaggedBatch([10] * (64 if base else 120), 196, dev)
+    qkv = torch.randn((rb.T, 3 * D), device=dev).to(bf)
+    o, lse = ops.attn_fwd(qkv, rb.cu_seqlens, rb.work, 2)
+    do = torch.randn((rb.T, D), device=dev).to(bf); dq = torch.empty_like(qkv); dl = torch.empty((2, rb.T), device=dev)
+    fn = (lambda: ops.attn_fwd(qkv, rb.cu_seqlens, rb.work, 2, out=o, lse=lse)) if "fwd" in name else \
+         (lambda: ops.attn_bwd(qkv, o, do, lse, rb.cu_seqlens, rb.work, 2, dqkv=dq, delta=dl))
 for _ in range(4): fn()
 torch.cuda.synchronize()
