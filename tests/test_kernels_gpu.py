@@ -60,14 +60,19 @@ def test_gemm_nt_epilogues(M, N, K):
     _close(out, (x.float() @ w.float().t()) * a.grad, 1e-2, 1e-2, "gelubwd")
 
 
-@pytest.mark.parametrize("T,I,J", [(1000, 2048, 192), (777, 192, 2048), (300, 576, 192), (256, 192, 192), (130, 256, 2048),
-                                   (64, 4096, 256), (5000, 192, 256), (900, 1152, 384), (333, 128, 64)])
-def test_gemm_tn(T, I, J):
+@pytest.mark.parametrize("T,I,J,ws_splits", [(1000, 2048, 192, 16), (777, 192, 2048, 16), (300, 576, 192, 16), (256, 192, 192, 16),
+                                             (130, 256, 2048, 16), (64, 4096, 256, 16), (5000, 192, 256, 16), (900, 1152, 384, 16),
+                                             (333, 128, 64, 16),
+                                             # the split rule of round 3: multiples of 8 that fill whole rounds of an XCD (many rows), the
+                                             # 192 x 192 tile of wide outputs, a workspace with room for fewer than eight splits, for one
+                                             (40000, 768, 768, 64), (20001, 2304, 768, 33), (9000, 384, 384, 64), (3000, 1152, 384, 5),
+                                             (1024, 4096, 256, 1), (70000, 576, 192, 200)])
+def test_gemm_tn(T, I, J, ws_splits):
     from chadavit_amd import ops
     dev = _dev()
     a = _rand((T, I), 5, 1.0).bfloat16().to(dev)
     b = _rand((T, J), 6, 1.0).bfloat16().to(dev)
-    ws = torch.empty(16 * (I * J + I), device=dev)
+    ws = torch.empty(ws_splits * (I * J + I), device=dev)
     c = torch.full((I, J), 7.0, device=dev)
     cs = torch.full((I,), 3.0, device=dev)
     ops.gemm_tn(a, b, c, colsum=cs, accumulate=False, workspace=ws)
