@@ -820,6 +820,27 @@ def main():
         for m_ in bbs:
             m_.cls_only_last_block = True
 
+    # ---- and, also for the record, WITHOUT the student's local-crop pass, which the reference computes and never reads
+    # (src/methods/dino.py:300-325 feeds only the global-crop logits to the loss); the headline runs it, as the reference does
+    value_nolocal = None
+    if getattr(model, "compute_unused_local_pass", False) and wl["n_local"] > 0 and not args.no_full_width_leg:
+        model.compute_unused_local_pass = False
+        n_nl = max(2, min(args.steps, 5))
+        for j in range(2):
+            tr.train_step(batch, args.warmup + args.steps + 8 + j)
+        barrier()
+        t1 = time.perf_counter()
+        for j in range(n_nl):
+            tr.train_step(batch, args.warmup + args.steps + 10 + j)
+        barrier()
+        dtn = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([dtn], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dtn = float(t.item())
+        value_nolocal = B * world * n_nl / dtn
+        model.compute_unused_local_pass = True
+
     # ---- roofline leg: launch counts of one recorded step, each distinct launch replayed between HIP events, the dominant one
     # timed again inside ordinary steps (launch_profile).  rocprofv3 --kernel-trace of this same command agrees (profiles/).
     prof_summary = None
@@ -856,6 +877,8 @@ def main():
         }
         if value_full is not None:
             out["config"]["images_per_s_with_full_width_last_block"] = round(value_full, 2)
+        if value_nolocal is not None:
+            out["config"]["images_per_s_without_the_unused_local_crop_pass"] = round(value_nolocal, 2)
         roof = None
         if prof_summary is not None:
             roof, out["launch_profile_top"] = roofline_object(prof_summary, model, nch, wl)
