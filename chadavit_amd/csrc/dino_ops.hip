@@ -181,6 +181,114 @@ __global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__
   }
 }
 
+// ---- BatchNorm1d of the DINO head's projector (reference src/methods/dino.py:59-77, use_bn=True) ------------------------------
+// z [N, C] bf16 (the Linear's output), statistics over the N rows of a column, training mode; C % 4 == 0.
+// bn_colsums_kernel: per column the two sums a BatchNorm pass needs -- MODE 0: (sum z, sum z^2); MODE 1 (backward):
+// (sum dy, sum dy * xhat) with xhat = (z - mean) * rstd.  64 columns per block (16 lanes x 4), 16 row groups, fixed-order LDS
+// reduction (deterministic).
+template <typename ZT> struct Z4 { typedef bf16x4 type; };
+template <> struct Z4<float> { typedef f32x4 type; };
+template <int MODE, typename ZT>
+__global__ __launch_bounds__(256) void bn_colsums_kernel(const ZT* __restrict__ z, const bf16_t* __restrict__ dy,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         float* __restrict__ s0, float* __restrict__ s1, int rows, int cols) {
+  __shared__ f32x4 part[2][16][16];
+  const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int c0 = blockIdx.x * 64 + cl * 4;
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+  if (c0 < cols) {
+    f32x4 mu = a0, rs = a0;
+    if (MODE == 1) { mu = *reinterpret_cast<const f32x4*>(mean + c0); rs = *reinterpret_cast<const f32x4*>(rstd + c0); }
+    for (int r = rg; r < rows; r += 16) {
+      const typename Z4<ZT>::type zv = *reinterpret_cast<const typename Z4<ZT>::type*>(z + (size_t)r * cols + c0);
+      if (MODE == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float v = (float)zv[e]; a0[e] += v; a1[e] = __builtin_fmaf(v, v, a1[e]); }
+      } else {
+        const bf16x4 dv = *reinterpret_cast<const bf16x4*>(dy + (size_t)r * cols + c0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = (float)dv[e]; a0[e] += d; a1[e] = __builtin_fmaf(d, ((float)zv[e] - mu[e]) * rs[e], a1[e]); }
+      }
+    }
+  }
+  part[0][rg][cl] = a0;
+  part[1][rg][cl] = a1;
+  __syncthreads();
+  if (rg == 0 && c0 < cols) {
+    f32x4 t0 = part[0][0][cl], t1 = part[1][0][cl];
+#pragma unroll
+    for (int g = 1; g < 16; ++g) { t0 += part[0][g][cl]; t1 += part[1][g][cl]; }
+    *reinterpret_cast<f32x4*>(s0 + c0) = t0;
+    *reinterpret_cast<f32x4*>(s1 + c0) = t1;
+  }
+}
+// (sum, sum of squares) -> mean, rstd (biased variance, as the normalisation uses it) and the running statistics
+// (momentum m, UNBIASED variance, torch.nn.BatchNorm1d); one thread per column
+__global__ __launch_bounds__(256) void bn_finish_kernel(const float* __restrict__ s0, const float* __restrict__ s1, float* __restrict__ mean,
+                                                        float* __restrict__ rstd, float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                        int rows, int cols, float eps, float momentum) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  const float inv = 1.0f / (float)rows;
+  const float mu = s0[c] * inv;
+  const float var = fmaxf(s1[c] * inv - mu * mu, 0.f);
+  mean[c] = mu;
+  rstd[c] = rsqrtf(var + eps);
+  if (run_mean) {
+    run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * mu;
+    run_var[c] = (1.0f - momentum) * run_var[c] + momentum * var * (rows > 1 ? (float)rows / (float)(rows - 1) : 1.0f);
+  }
+}
+// y = (z - mean) * rstd * gamma + beta -> pre (bf16: the GELU's input, kept for the backward) and act = gelu(y)
+template <typename ZT>
+__global__ __launch_bounds__(256) void bn_apply_gelu_kernel(const ZT* __restrict__ z, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, bf16_t* __restrict__ pre,
+                                                            bf16_t* __restrict__ act, long long n4, int cols) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256ll) {
+    const int c = (int)((i * 4) % cols);
+    const typename Z4<ZT>::type zv = *reinterpret_cast<const typename Z4<ZT>::type*>(z + i * 4);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), rs = *reinterpret_cast<const f32x4*>(rstd + c);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c), be = *reinterpret_cast<const f32x4*>(beta + c);
+    bf16x4 p, a;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float y = __builtin_fmaf(((float)zv[e] - mu[e]) * rs[e], ga[e], be[e]);
+      p[e] = (bf16_t)y;
+      a[e] = (bf16_t)gelu_erf((float)p[e]);   // the GELU of the ROUNDED pre-activation: what the backward differentiates
+    }
+    *reinterpret_cast<bf16x4*>(pre + i * 4) = p;
+    *reinterpret_cast<bf16x4*>(act + i * 4) = a;
+  }
+}
+// dz = gamma * rstd * (dy - sum(dy) / N - xhat * sum(dy xhat) / N)
+template <typename ZT>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restrict__ dy, const ZT* __restrict__ z,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ sdy,
+                                                           const float* __restrict__ sdyx, bf16_t* __restrict__ dz, long long n4, int cols,
+                                                           float inv_rows) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256ll) {
+    const int c = (int)((i * 4) % cols);
+    const bf16x4 dv = *reinterpret_cast<const bf16x4*>(dy + i * 4);
+    const typename Z4<ZT>::type zv = *reinterpret_cast<const typename Z4<ZT>::type*>(z + i * 4);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), rs = *reinterpret_cast<const f32x4*>(rstd + c);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
+    const f32x4 a = *reinterpret_cast<const f32x4*>(sdy + c), b = *reinterpret_cast<const f32x4*>(sdyx + c);
+    bf16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float xh = ((float)zv[e] - mu[e]) * rs[e];
+      o[e] = (bf16_t)(ga[e] * rs[e] * ((float)dv[e] - a[e] * inv_rows - xh * b[e] * inv_rows));
+    }
+    *reinterpret_cast<bf16x4*>(dz + i * 4) = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ dst, const float* __restrict__ src, int accumulate, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = (accumulate ? dst[i] : 0.f) + src[i];
+}
 __global__ __launch_bounds__(256) void center_ema_kernel(float* __restrict__ center, const float* __restrict__ colsum,
                                                          float inv_count, float momentum, int P) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -448,7 +556,7 @@ __global__ __launch_bounds__(256) void knn_vote_kernel(const float* __restrict__
 
 }  // namespace
 
-extern "C" int chadavit_abi_version(void) { return 4; }
+extern "C" int chadavit_abi_version(void) { return 5; }
 
 extern "C" int chadavit_l2norm_fwd(const float* x, chada_bf16* y, float* inv_norm, int M, int N, void* stream) {
   CHADA_ENTRY();
@@ -508,6 +616,70 @@ extern "C" int chadavit_center_ema(float* center, const float* colsum, float inv
   CHADA_CHECK_LAUNCH();
   return 0;
 }
+// BatchNorm1d of the head's projector (src/methods/dino.py:59-77 with use_bn=True), training-mode statistics over the rows.
+// z = the Linear's output, fp32 (z_f32 != 0: what the head uses -- the statistics of a handful of rows do not survive bf16 rounding of
+// their inputs) or bf16.
+// chadavit_bn_stats: mean / rstd of every column of z [N, C] (workspace: 2 C floats); running_mean / running_var (optional) get
+// torch.nn.BatchNorm1d's update (momentum, unbiased variance).
+extern "C" int chadavit_bn_stats(const void* z, int z_f32, int N, int C, float eps, float* mean, float* rstd, float* running_mean,
+                                 float* running_var, float momentum, float* workspace, void* stream) {
+  CHADA_ENTRY();
+  if (!z || !mean || !rstd || !workspace || N <= 0 || C <= 0 || (running_mean == nullptr) != (running_var == nullptr)) return 1;
+  if (C % 4 != 0 || ((uintptr_t)z & 15) != 0) return 2;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (z_f32)
+    hipLaunchKernelGGL((bn_colsums_kernel<0, float>), dim3((C + 63) / 64), dim3(256), 0, s, reinterpret_cast<const float*>(z), (const bf16_t*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, workspace, workspace + C, N, C);
+  else
+    hipLaunchKernelGGL((bn_colsums_kernel<0, bf16_t>), dim3((C + 63) / 64), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(z), (const bf16_t*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, workspace, workspace + C, N, C);
+  hipLaunchKernelGGL(bn_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, s, workspace, workspace + C, mean, rstd, running_mean, running_var, N,
+                     C, eps, momentum);
+  CHADA_CHECK_LAUNCH();
+  return 0;
+}
+// pre = (z - mean) rstd gamma + beta (bf16), act = gelu(pre) (bf16)
+extern "C" int chadavit_bn_apply_gelu(const void* z, int z_f32, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                      chada_bf16* pre, chada_bf16* act, int N, int C, void* stream) {
+  CHADA_ENTRY();
+  if (!z || !mean || !rstd || !gamma || !beta || !pre || !act || N <= 0 || C <= 0) return 1;
+  if (C % 4 != 0) return 2;
+  const long long n4 = (long long)N * C / 4;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (z_f32)
+    hipLaunchKernelGGL((bn_apply_gelu_kernel<float>), dim3(grid_for((size_t)n4, 4096)), dim3(256), 0, s, reinterpret_cast<const float*>(z), mean, rstd,
+                       gamma, beta, reinterpret_cast<bf16_t*>(pre), reinterpret_cast<bf16_t*>(act), n4, C);
+  else
+    hipLaunchKernelGGL((bn_apply_gelu_kernel<bf16_t>), dim3(grid_for((size_t)n4, 4096)), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(z), mean, rstd,
+                       gamma, beta, reinterpret_cast<bf16_t*>(pre), reinterpret_cast<bf16_t*>(act), n4, C);
+  CHADA_CHECK_LAUNCH();
+  return 0;
+}
+// backward: dy = gradient w.r.t. the BatchNorm output.  dgamma / dbeta (+= when accumulate) and dz (bf16); workspace: 2 C floats
+extern "C" int chadavit_bn_bwd(const chada_bf16* dy, const void* z, int z_f32, const float* mean, const float* rstd, const float* gamma,
+                               float* dgamma, float* dbeta, int accumulate, chada_bf16* dz, int N, int C, float* workspace, void* stream) {
+  CHADA_ENTRY();
+  if (!dy || !z || !mean || !rstd || !gamma || !dgamma || !dbeta || !dz || !workspace || N <= 0 || C <= 0) return 1;
+  if (C % 4 != 0) return 2;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const long long n4 = (long long)N * C / 4;
+  if (z_f32) {
+    hipLaunchKernelGGL((bn_colsums_kernel<1, float>), dim3((C + 63) / 64), dim3(256), 0, s, reinterpret_cast<const float*>(z),
+                       reinterpret_cast<const bf16_t*>(dy), mean, rstd, workspace, workspace + C, N, C);
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(grid_for((size_t)n4, 4096)), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(dy),
+                       reinterpret_cast<const float*>(z), mean, rstd, gamma, workspace, workspace + C, reinterpret_cast<bf16_t*>(dz), n4, C, 1.0f / (float)N);
+  } else {
+    hipLaunchKernelGGL((bn_colsums_kernel<1, bf16_t>), dim3((C + 63) / 64), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(z),
+                       reinterpret_cast<const bf16_t*>(dy), mean, rstd, workspace, workspace + C, N, C);
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t>), dim3(grid_for((size_t)n4, 4096)), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(dy),
+                       reinterpret_cast<const bf16_t*>(z), mean, rstd, gamma, workspace, workspace + C, reinterpret_cast<bf16_t*>(dz), n4, C, 1.0f / (float)N);
+  }
+  hipLaunchKernelGGL(axpy_kernel, dim3((C + 255) / 256), dim3(256), 0, s, dbeta, workspace, accumulate, C);
+  hipLaunchKernelGGL(axpy_kernel, dim3((C + 255) / 256), dim3(256), 0, s, dgamma, workspace + C, accumulate, C);
+  CHADA_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int chadavit_sum_rows_f32(const float* x, float* out, int rows, int cols, float scale, void* stream) {
   CHADA_ENTRY();
   if (!x || !out || rows <= 0 || cols <= 0) return 1;

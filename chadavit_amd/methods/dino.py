@@ -75,18 +75,28 @@ except Exception:  # noqa: BLE001
 # DINO head
 # ==============================================================================================
 class DINOHead(nn.Module):
-    """MLP(D -> hidden -> hidden -> bottleneck, GELU) -> L2 normalise -> weight-normed prototypes
-    (reference dino.py:32-111).  Parameter names: mlp.{0,2,4}.{weight,bias}, last_layer.weight_{g,v}."""
+    """MLP(D -> hidden -> hidden -> bottleneck, GELU; optional BatchNorm1d after the first two Linears) -> L2 normalise ->
+    weight-normed prototypes (reference dino.py:32-111).  Parameter names as the reference's nn.Sequential gives them:
+    mlp.{0,2,4}.{weight,bias} without BatchNorm, mlp.{0,3,6} + BatchNorm at mlp.{1,4} (with their running_* buffers) with
+    `use_bn` (cfg `method_kwargs.use_bn_in_head`); last_layer.weight_{g,v}."""
 
     def __init__(self, in_dim: int, num_prototypes: int, use_bn: bool = True, norm_last_layer: bool = True,
                  num_layers: int = 3, hidden_dim: int = 2048, bottleneck_dim: int = 256):
         super().__init__()
-        if use_bn:
-            raise RuntimeError("chadavit_amd DINOHead: use_bn_in_head=True is not supported (reference default is False)")
         if max(num_layers, 1) != 3:
             raise RuntimeError("chadavit_amd DINOHead: only the 3-layer projector of the reference configs is supported")
-        self.mlp = nn.Sequential(nn.Linear(in_dim, hidden_dim), nn.GELU(), nn.Linear(hidden_dim, hidden_dim), nn.GELU(),
-                                 nn.Linear(hidden_dim, bottleneck_dim))
+        self.use_bn = bool(use_bn)
+        if self.use_bn:
+            if hidden_dim % 4 != 0:
+                raise RuntimeError("chadavit_amd DINOHead: use_bn needs hidden_dim % 4 == 0")
+            self.mlp = nn.Sequential(nn.Linear(in_dim, hidden_dim), nn.BatchNorm1d(hidden_dim), nn.GELU(),
+                                     nn.Linear(hidden_dim, hidden_dim), nn.BatchNorm1d(hidden_dim), nn.GELU(),
+                                     nn.Linear(hidden_dim, bottleneck_dim))
+            self._lin, self._bn = ("mlp.0", "mlp.3", "mlp.6"), ("mlp.1", "mlp.4")
+        else:
+            self.mlp = nn.Sequential(nn.Linear(in_dim, hidden_dim), nn.GELU(), nn.Linear(hidden_dim, hidden_dim), nn.GELU(),
+                                     nn.Linear(hidden_dim, bottleneck_dim))
+            self._lin, self._bn = ("mlp.0", "mlp.2", "mlp.4"), ()
         self.apply(self._init_weights)
         self.last_layer = nn.utils.weight_norm(nn.Linear(bottleneck_dim, num_prototypes, bias=False))
         self.last_layer.weight_g.data.fill_(1)
@@ -97,6 +107,7 @@ class DINOHead(nn.Module):
         self._tn_ws = None
         self.skip_last_layer_grad = False  # set by DINO while epoch < freeze_last_layer (grads would be dropped)
         self.grad_ready_hook = None
+        self._pending_backwards = 0
 
     @staticmethod
     def _init_weights(m: nn.Module):
@@ -110,7 +121,7 @@ class DINOHead(nn.Module):
         if dev.type != "cuda":
             raise RuntimeError("DINOHead (chadavit_amd) runs on the GPU only")
         if self._flat is None or self._flat.device != dev or not self._flat.attached():
-            self._flat = FlatParams(list(self.named_parameters()), dev, transpose_names=["mlp.0.weight", "mlp.2.weight", "mlp.4.weight"])
+            self._flat = FlatParams(list(self.named_parameters()), dev, transpose_names=[n + ".weight" for n in self._lin])
             self._proto = None
         return self._flat
 
@@ -139,18 +150,43 @@ class _HeadFn(torch.autograd.Function):
         xb = x.to(torch.bfloat16).contiguous()
         M = xb.shape[0]
         dev = x.device
-        hid = flat.shapes["mlp.0.weight"][0]
-        pre1 = torch.empty((M, hid), device=dev, dtype=torch.bfloat16)
-        pre2 = torch.empty((M, hid), device=dev, dtype=torch.bfloat16)
-        h1 = ops.gemm_nt(xb, flat.w("mlp.0.weight"), bias=flat.f("mlp.0.bias"), epilogue=ops.EPI_GELU, aux_out=pre1)
-        h2 = ops.gemm_nt(h1, flat.w("mlp.2.weight"), bias=flat.f("mlp.2.bias"), epilogue=ops.EPI_GELU, aux_out=pre2)
-        t = ops.gemm_nt(h2, flat.w("mlp.4.weight"), bias=flat.f("mlp.4.bias"), out_fp32=True)
+        L0, L1, L2 = head._lin
+        hid = flat.shapes[L0 + ".weight"][0]
+        bn_saved = None
+        if head.use_bn:
+            # Linear -> BatchNorm1d (statistics over the rows of this call, dino.py:66-72) -> GELU, twice
+            if need_grad and not head.training:
+                raise RuntimeError("chadavit_amd DINOHead: gradients through BatchNorm in eval mode are not supported")
+            bn_saved = []
+            act = xb
+            for li, bi in ((L0, 0), (L1, 1)):
+                bn = head.mlp[int(head._bn[bi].split(".")[1])]
+                z = ops.gemm_nt(act, flat.w(li + ".weight"), bias=flat.f(li + ".bias"), out_fp32=True)   # fp32: the statistics of a crop's few rows
+                if head.training:
+                    mean, rstd = ops.bn_stats(z, bn.eps, bn.running_mean, bn.running_var, bn.momentum if bn.momentum is not None else 0.1)
+                    bn.num_batches_tracked += 1
+                else:
+                    mean, rstd = bn.running_mean, torch.rsqrt(bn.running_var + bn.eps)
+                pre, nxt = ops.bn_apply_gelu(z, mean, rstd, flat.f(head._bn[bi] + ".weight"), flat.f(head._bn[bi] + ".bias"))
+                bn_saved.append((z, mean, rstd))
+                if bi == 0:
+                    pre1, h1 = pre, nxt
+                else:
+                    pre2, h2 = pre, nxt
+                act = nxt
+        else:
+            pre1 = torch.empty((M, hid), device=dev, dtype=torch.bfloat16)
+            pre2 = torch.empty((M, hid), device=dev, dtype=torch.bfloat16)
+            h1 = ops.gemm_nt(xb, flat.w(L0 + ".weight"), bias=flat.f(L0 + ".bias"), epilogue=ops.EPI_GELU, aux_out=pre1)
+            h2 = ops.gemm_nt(h1, flat.w(L1 + ".weight"), bias=flat.f(L1 + ".bias"), epilogue=ops.EPI_GELU, aux_out=pre2)
+        t = ops.gemm_nt(h2, flat.w(L2 + ".weight"), bias=flat.f(L2 + ".bias"), out_fp32=True)
         tn, tinv = ops.l2norm_fwd(t)
         logits = ops.gemm_nt(tn, w, out_fp32=True)
         ctx.head, ctx.need_grad, ctx.n_params = head, need_grad, len(params)
         ctx.x_needs_grad = x.requires_grad
         if need_grad:
             ctx.saved = (xb, pre1, h1, pre2, h2, t, tn, tinv, wt, winv)
+            ctx.bn_saved = bn_saved
         return logits
 
     @staticmethod
@@ -164,13 +200,14 @@ class _HeadFn(torch.autograd.Function):
         G = flat.g
         if head._tn_ws is None or head._tn_ws.device != dev:
             P, K = flat.shapes["last_layer.weight_v"]
-            hid = flat.shapes["mlp.2.weight"][0]
+            hid = flat.shapes[head._lin[1] + ".weight"][0]
             # eight T-splits of the widest gradient: one per XCD (chadavit_gemm_tn sends split s to XCD s % 8; with room for two, the
             # prototype layer's gradient ran on two XCDs)
             head._tn_ws = torch.empty(8 * max(P * K + P, hid * hid + hid), device=dev, dtype=torch.float32)
         ws = head._tn_ws
+        L0, L1, L2 = head._lin
         w0 = head.mlp[0].weight
-        acc = w0.grad is not None and w0.grad.data_ptr() == G("mlp.0.weight").data_ptr()
+        acc = w0.grad is not None and w0.grad.data_ptr() == G(L0 + ".weight").data_ptr()
         if w0.grad is not None and not acc:
             for n, p in zip(flat.names, flat.params):
                 if p.grad is not None:
@@ -187,16 +224,25 @@ class _HeadFn(torch.autograd.Function):
         elif not acc:
             G(vname).zero_()
         dt = ops.l2norm_bwd(dtn, t, tinv)
-        dh2 = ops.gemm_nt(dt, flat.wt("mlp.4.weight"), epilogue=ops.EPI_GELUBWD, aux=pre2)
-        ops.gemm_tn(dt, h2, G("mlp.4.weight"), colsum=G("mlp.4.bias"), accumulate=acc, workspace=ws)
-        dh1 = ops.gemm_nt(dh2, flat.wt("mlp.2.weight"), epilogue=ops.EPI_GELUBWD, aux=pre1)
-        ops.gemm_tn(dh2, h1, G("mlp.2.weight"), colsum=G("mlp.2.bias"), accumulate=acc, workspace=ws)
-        dx = ops.gemm_nt(dh1, flat.wt("mlp.0.weight"), out_fp32=True) if ctx.x_needs_grad else None
-        ops.gemm_tn(dh1, xb, G("mlp.0.weight"), colsum=G("mlp.0.bias"), accumulate=acc, workspace=ws)
+        dh2 = ops.gemm_nt(dt, flat.wt(L2 + ".weight"), epilogue=ops.EPI_GELUBWD, aux=pre2)   # gradient w.r.t. the second GELU's input
+        ops.gemm_tn(dt, h2, G(L2 + ".weight"), colsum=G(L2 + ".bias"), accumulate=acc, workspace=ws)
+        if head.use_bn:   # ... which is the second BatchNorm's output
+            (z1, m1, r1), (z2, m2, r2) = ctx.bn_saved
+            B0, B1 = head._bn
+            dh2 = ops.bn_bwd(dh2, z2, m2, r2, flat.f(B1 + ".weight"), G(B1 + ".weight"), G(B1 + ".bias"), accumulate=acc)
+        dh1 = ops.gemm_nt(dh2, flat.wt(L1 + ".weight"), epilogue=ops.EPI_GELUBWD, aux=pre1)
+        ops.gemm_tn(dh2, h1, G(L1 + ".weight"), colsum=G(L1 + ".bias"), accumulate=acc, workspace=ws)
+        if head.use_bn:
+            dh1 = ops.bn_bwd(dh1, z1, m1, r1, flat.f(B0 + ".weight"), G(B0 + ".weight"), G(B0 + ".bias"), accumulate=acc)
+        dx = ops.gemm_nt(dh1, flat.wt(L0 + ".weight"), out_fp32=True) if ctx.x_needs_grad else None
+        ops.gemm_tn(dh1, xb, G(L0 + ".weight"), colsum=G(L0 + ".bias"), accumulate=acc, workspace=ws)
         for n, p in zip(flat.names, flat.params):
             if p.requires_grad and not (n == vname and head.skip_last_layer_grad):
                 p.grad = G(n)
-        if head.grad_ready_hook is not None:
+        pending = getattr(head, "_pending_backwards", 0)
+        if pending > 1:   # (BatchNorm: one head call per crop -- the gradient slab is complete after the last of their backwards)
+            head._pending_backwards = pending - 1
+        elif head.grad_ready_hook is not None:
             head.grad_ready_hook(flat, 0, flat.numel)
         return (None, dx, None) + (None,) * ctx.n_params
 
@@ -420,6 +466,17 @@ class DINO(_Base):
         self.dino_loss_func.epoch = self.current_epoch
 
     # ------------------------------------------------------------------------------------------
+    @staticmethod
+    def _head_per_crop(head: "DINOHead", feats: torch.Tensor, n_crops: int) -> torch.Tensor:
+        """The head on the features of `n_crops` crops stacked row-wise.  Without BatchNorm one call; with it one call per crop, as the
+        reference makes them (base.py:690-700 runs `self(x)` crop by crop): BatchNorm1d's statistics are those of one crop's rows and
+        its running estimates move once per crop."""
+        if not head.use_bn or n_crops == 1:
+            head._pending_backwards = 0
+            return head(feats)
+        head._pending_backwards = n_crops if torch.is_grad_enabled() else 0
+        return torch.cat([head(f) for f in feats.chunk(n_crops)])
+
     def training_step(self, batch: Sequence[Any], batch_idx: int) -> torch.Tensor:
         """Reference flow: base.py:668-733 (student), :1186-1248 (teacher), dino.py:300-325 (loss)."""
         X, targets, list_num_channels = batch
@@ -460,17 +517,18 @@ class DINO(_Base):
                 s_local.wait_stream(main)
                 xg.record_stream(s_teacher)
                 with torch.cuda.stream(s_teacher), torch.no_grad():
-                    momentum_p = self.momentum_head(self.momentum_backbone.forward_ragged(xg, nch, rb=rbg))
+                    momentum_p = self._head_per_crop(self.momentum_head, self.momentum_backbone.forward_ragged(xg, nch, rb=rbg), nl)
             feats = self.backbone.forward_ragged(xg, nch, rb=rbg)
-            p = self.head(feats)
+            p = self._head_per_crop(self.head, feats, nl)
             feats_list = list(feats.chunk(nl))
             if use_streams:
                 main.wait_stream(s_teacher)
                 momentum_p.record_stream(main)
             else:
                 with torch.no_grad():
-                    momentum_p = self.momentum_head(self.momentum_backbone.forward_ragged(xg, nch, rb=rbg))
+                    momentum_p = self._head_per_crop(self.momentum_head, self.momentum_backbone.forward_ragged(xg, nch, rb=rbg), nl)
         else:
+            self.head._pending_backwards = nl if (self.head.use_bn and torch.is_grad_enabled()) else 0
             outs = [self(x, k) for k, x in enumerate(X[:nl])]
             p = torch.cat([o["z"] for o in outs])
             feats_list = [o["feats"] for o in outs]

@@ -657,6 +657,57 @@ def sum_rows_f32(x, scale=1.0):
     return out
 
 
+def _req_z(z):
+    if z.dtype == F32:
+        _req(z, F32, "z")
+    else:
+        _req(z, BF16, "z")
+
+
+@_timed(lambda z, *a, **k: ("bn_stats", z.shape[0], z.shape[1]))
+def bn_stats(z, eps, running_mean=None, running_var=None, momentum=0.1):
+    """Column statistics of z (N, C) bf16 for BatchNorm1d in training mode: (mean, rstd); the running estimates are updated in place
+    when given (torch.nn.BatchNorm1d: momentum, unbiased variance)."""
+    _req_z(z)
+    N, C = z.shape
+    mean = torch.empty((C,), device=z.device, dtype=F32)
+    rstd = torch.empty((C,), device=z.device, dtype=F32)
+    ws = torch.empty((2 * C,), device=z.device, dtype=F32)
+    for t, nm in ((running_mean, "running_mean"), (running_var, "running_var")):
+        if t is not None:
+            _req(t, F32, nm)
+    _chk(lib().chadavit_bn_stats(_ptr(z), c_int(int(z.dtype == F32)), c_int(N), c_int(C), c_float(eps), _ptr(mean), _ptr(rstd), _ptr(running_mean), _ptr(running_var),
+                                 c_float(momentum), _ptr(ws), _stream()), "chadavit_bn_stats")
+    return mean, rstd
+
+
+def bn_apply_gelu(z, mean, rstd, gamma, beta):
+    """(pre, act): pre = (z - mean) * rstd * gamma + beta, act = gelu(pre); both bf16 (N, C)."""
+    _req_z(z)
+    for t, nm in ((mean, "mean"), (rstd, "rstd"), (gamma, "gamma"), (beta, "beta")):
+        _req(t, F32, nm)
+    N, C = z.shape
+    pre = torch.empty((N, C), device=z.device, dtype=BF16)
+    act = torch.empty((N, C), device=z.device, dtype=BF16)
+    _chk(lib().chadavit_bn_apply_gelu(_ptr(z), c_int(int(z.dtype == F32)), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(pre), _ptr(act), c_int(N), c_int(C),
+                                      _stream()), "chadavit_bn_apply_gelu")
+    return pre, act
+
+
+@_timed(lambda dy, z, *a, **k: ("bn_bwd", z.shape[0], z.shape[1]))
+def bn_bwd(dy, z, mean, rstd, gamma, dgamma, dbeta, accumulate=False):
+    """BatchNorm1d backward (training-mode statistics): dgamma / dbeta written (or added to) in place, returns dz (bf16)."""
+    _req(dy, BF16, "dy"); _req_z(z)
+    for t, nm in ((mean, "mean"), (rstd, "rstd"), (gamma, "gamma"), (dgamma, "dgamma"), (dbeta, "dbeta")):
+        _req(t, F32, nm)
+    N, C = z.shape
+    dz = torch.empty((N, C), device=z.device, dtype=BF16)
+    ws = torch.empty((2 * C,), device=z.device, dtype=F32)
+    _chk(lib().chadavit_bn_bwd(_ptr(dy), _ptr(z), c_int(int(z.dtype == F32)), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(dgamma), _ptr(dbeta), c_int(1 if accumulate else 0),
+                               _ptr(dz), c_int(N), c_int(C), _ptr(ws), _stream()), "chadavit_bn_bwd")
+    return dz
+
+
 def ema_update(teacher, student, tau):
     _req(teacher, F32, "teacher"); _req(student, F32, "student")
     _chk(lib().chadavit_ema_update(_ptr(teacher), _ptr(student), c_float(tau), c_ll(teacher.numel()), _stream()), "chadavit_ema_update")

@@ -324,6 +324,20 @@ int chadavit_clip_tensors(float* grads, const long long* offsets, const long lon
                           void* stream);
 int chadavit_sum_rows_f32(const float* x, float* out, int rows, int cols, float scale, void* stream);
 
+/* ---- BatchNorm1d of the DINO head's projector (reference src/methods/dino.py:59-77, `use_bn_in_head`; torch.nn.BatchNorm1d in
+ * training mode: statistics over the N rows of each of the C columns, biased variance for the normalisation, unbiased for the
+ * running estimate).  z: the Linear's output [N, C], fp32 (z_f32 != 0) or bf16; pre / act / dy / dz: bf16 [N, C]; row-major, C % 4 == 0;
+ * workspace: 2 C floats.
+ * chadavit_bn_stats: mean[C], rstd[C] = 1 / sqrt(var + eps); running_mean / running_var (both or neither) updated with `momentum`.
+ * chadavit_bn_apply_gelu: pre = (z - mean) rstd gamma + beta, act = gelu(pre) (the nn.GELU that follows, dino.py:68).
+ * chadavit_bn_bwd: dy = gradient w.r.t. the BatchNorm output; dgamma, dbeta (+= when accumulate), dz. */
+int chadavit_bn_stats(const void* z, int z_f32, int N, int C, float eps, float* mean, float* rstd, float* running_mean, float* running_var,
+                      float momentum, float* workspace, void* stream);
+int chadavit_bn_apply_gelu(const void* z, int z_f32, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                           chada_bf16* pre, chada_bf16* act, int N, int C, void* stream);
+int chadavit_bn_bwd(const chada_bf16* dy, const void* z, int z_f32, const float* mean, const float* rstd, const float* gamma, float* dgamma,
+                    float* dbeta, int accumulate, chada_bf16* dz, int N, int C, float* workspace, void* stream);
+
 /* ---- fp8 weight path (BASELINE.json configs[4]: ChAda-ViT-Base) -------------------------------------------------------------
  * OCP MX fp8: e4m3fn elements + one E8M0 power-of-two scale per 32 consecutive k of a row (the form gfx950's
  * v_mfma_scale_f32_16x16x128_f8f6f4 multiplies at twice the bf16 MFMA rate).  Replaces the nn.Linear forwards of the encoder block

@@ -247,10 +247,22 @@ def last_selfattention(p: Params, x: torch.Tensor, nheads: int = 2, patch: int =
 # ======================================================================================
 # A8  DINO head  (src/methods/dino.py:98-111)
 # ======================================================================================
-def head_forward(hp: Params, f: torch.Tensor) -> torch.Tensor:
-    t = F.gelu(f @ hp["mlp.0.weight"].t() + hp["mlp.0.bias"])
-    t = F.gelu(t @ hp["mlp.2.weight"].t() + hp["mlp.2.bias"])
-    t = t @ hp["mlp.4.weight"].t() + hp["mlp.4.bias"]
+def head_forward(hp: Params, f: torch.Tensor, bn_stats: Optional[Dict[str, torch.Tensor]] = None, training: bool = True) -> torch.Tensor:
+    """DINOHead.forward (src/methods/dino.py:98-111).  With `use_bn` (keys mlp.6.* present: Linear, BatchNorm1d, GELU, Linear,
+    BatchNorm1d, GELU, Linear -- dino.py:59-77) `bn_stats` holds the running estimates {"mlp.1.running_mean", ...}; they are
+    updated in place in training mode, exactly as torch.nn.BatchNorm1d does (momentum 0.1, eps 1e-5)."""
+    if "mlp.6.weight" in hp:
+        t = f
+        for lin, bn in (("mlp.0", "mlp.1"), ("mlp.3", "mlp.4")):
+            t = t @ hp[lin + ".weight"].t() + hp[lin + ".bias"]
+            rm = bn_stats[bn + ".running_mean"] if bn_stats is not None else None
+            rv = bn_stats[bn + ".running_var"] if bn_stats is not None else None
+            t = F.gelu(F.batch_norm(t, rm, rv, hp[bn + ".weight"], hp[bn + ".bias"], training or rm is None, 0.1, 1e-5))
+        t = t @ hp["mlp.6.weight"].t() + hp["mlp.6.bias"]
+    else:
+        t = F.gelu(f @ hp["mlp.0.weight"].t() + hp["mlp.0.bias"])
+        t = F.gelu(t @ hp["mlp.2.weight"].t() + hp["mlp.2.bias"])
+        t = t @ hp["mlp.4.weight"].t() + hp["mlp.4.bias"]
     t = F.normalize(t, dim=-1)  # eps 1e-12
     v = hp["last_layer.weight_v"]
     w = hp["last_layer.weight_g"] * v / v.norm(dim=1, keepdim=True)  # old-style weight_norm, dim=0
@@ -327,19 +339,24 @@ def training_step(sd: Params, crops: List[torch.Tensor], num_channels: List[List
     ``sd`` uses the method-level keys ``backbone.*``, ``momentum_backbone.*``, ``head.*``,
     ``momentum_head.*``, ``dino_loss_func.center``."""
     bb = {k: v.detach().clone().requires_grad_(True) for k, v in split_prefix(sd, "backbone.").items()}
-    hd = {k: v.detach().clone().requires_grad_(k != "last_layer.weight_g") for k, v in split_prefix(sd, "head.").items()}
+    hd_all, thd_all = split_prefix(sd, "head."), split_prefix(sd, "momentum_head.")
+    is_buf = lambda k: k.endswith(("running_mean", "running_var", "num_batches_tracked"))
+    hd = {k: v.detach().clone().requires_grad_(k != "last_layer.weight_g") for k, v in hd_all.items() if not is_buf(k)}
     tbb = split_prefix(sd, "momentum_backbone.")
-    thd = split_prefix(sd, "momentum_head.")
+    thd = {k: v for k, v in thd_all.items() if not is_buf(k)}
+    # BatchNorm running estimates of the two heads (use_bn_in_head): cloned, updated once per head call (= per global crop)
+    hbn = {k: v.detach().clone() for k, v in hd_all.items() if is_buf(k) and v.is_floating_point()} or None
+    tbn = {k: v.detach().clone() for k, v in thd_all.items() if is_buf(k) and v.is_floating_point()} or None
     fwd = backbone_padded if padded else backbone_ragged
     feats, z = [], []
     for k in range(num_large_crops):
         f = fwd(bb, crops[k], num_channels[k], nheads)
         feats.append(f)
-        z.append(head_forward(hd, f))
+        z.append(head_forward(hd, f, hbn))
     with torch.no_grad():
         for k in range(num_large_crops, len(crops)):  # local crops: forward only, no loss (SURVEY A7)
             feats.append(fwd(bb, crops[k], num_channels[k], nheads))
-        tz = [head_forward(thd, fwd(tbb, crops[k], num_channels[k], nheads)) for k in range(num_large_crops)]
+        tz = [head_forward(thd, fwd(tbb, crops[k], num_channels[k], nheads), tbn) for k in range(num_large_crops)]
     p_s = torch.cat(z)
     p_t = torch.cat(tz)
     center = sd["dino_loss_func.center"]
@@ -360,7 +377,7 @@ def training_step(sd: Params, crops: List[torch.Tensor], num_channels: List[List
             g = None
         grads["head." + k] = g
     new_center = center_update(center, p_t)
-    aux = {"student_logits": p_s.detach(), "teacher_logits": p_t, "feats": [f.detach() for f in feats]}
+    aux = {"student_logits": p_s.detach(), "teacher_logits": p_t, "feats": [f.detach() for f in feats], "head_bn": hbn, "momentum_head_bn": tbn}
     return loss.detach(), grads, new_center, aux
 
 

@@ -64,7 +64,7 @@ def _scale_for(name: str, shape: Tuple[int, ...]) -> Tuple[float, float]:
     """(scale, shift) per parameter kind.  Chosen so activations stay O(1) through 12 post-norm
     blocks and no LayerNorm / bias parameter is at its trivial init (so parity tests see them)."""
     leaf = name.split(".")[-1]
-    if "norm" in name and leaf == "weight":
+    if ("norm" in name or len(shape) == 1) and leaf == "weight":   # LayerNorm / BatchNorm gamma
         return 0.25, 1.0
     if leaf in ("bias", "in_proj_bias"):
         return 0.10, 0.0
@@ -121,8 +121,19 @@ def backbone_shapes(embed_dim: int, depth: int = 12, patch: int = 16, img: int =
     return s
 
 
-def head_shapes(in_dim: int, hidden: int = 2048, bottleneck: int = 256, prototypes: int = 4096) -> Dict[str, Tuple[int, ...]]:
-    """state_dict layout of reference DINOHead (dino.py:59-84), use_bn=False."""
+def head_shapes(in_dim: int, hidden: int = 2048, bottleneck: int = 256, prototypes: int = 4096, use_bn: bool = False) -> Dict[str, Tuple[int, ...]]:
+    """state_dict layout of reference DINOHead (dino.py:59-84): use_bn=False by default; with use_bn the Sequential gains a
+    BatchNorm1d after each of the first two Linears (mlp.1, mlp.4; their running statistics are buffers and keep torch's init)."""
+    if use_bn:
+        return {
+            "mlp.0.weight": (hidden, in_dim), "mlp.0.bias": (hidden,),
+            "mlp.1.weight": (hidden,), "mlp.1.bias": (hidden,),
+            "mlp.3.weight": (hidden, hidden), "mlp.3.bias": (hidden,),
+            "mlp.4.weight": (hidden,), "mlp.4.bias": (hidden,),
+            "mlp.6.weight": (bottleneck, hidden), "mlp.6.bias": (bottleneck,),
+            "last_layer.weight_g": (prototypes, 1),
+            "last_layer.weight_v": (prototypes, bottleneck),
+        }
     return {
         "mlp.0.weight": (hidden, in_dim), "mlp.0.bias": (hidden,),
         "mlp.2.weight": (hidden, hidden), "mlp.2.bias": (hidden,),

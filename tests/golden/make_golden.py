@@ -81,24 +81,31 @@ def golden_backbone(name, D, nch, sizes, seed_w, seed_x, nheads_direct=None):
 
 
 # --------------------------------------------------------------------------------------
-def build_sd(D, PR, seeds=(1, 2, 3, 4, 5), hidden=2048, bott=256):
+def build_sd(D, PR, seeds=(1, 2, 3, 4, 5), hidden=2048, bott=256, use_bn=False):
     sd = {}
     sd.update({"backbone." + k: v for k, v in P.fill_state_dict(P.backbone_shapes(D), seed=seeds[0]).items()})
     sd.update({"momentum_backbone." + k: v for k, v in P.fill_state_dict(P.backbone_shapes(D), seed=seeds[1]).items()})
-    sd.update({"head." + k: v for k, v in P.fill_state_dict(P.head_shapes(D, hidden, bott, PR), seed=seeds[2]).items()})
-    sd.update({"momentum_head." + k: v for k, v in P.fill_state_dict(P.head_shapes(D, hidden, bott, PR), seed=seeds[3]).items()})
+    sd.update({"head." + k: v for k, v in P.fill_state_dict(P.head_shapes(D, hidden, bott, PR, use_bn=use_bn), seed=seeds[2]).items()})
+    sd.update({"momentum_head." + k: v for k, v in P.fill_state_dict(P.head_shapes(D, hidden, bott, PR, use_bn=use_bn), seed=seeds[3]).items()})
+    if use_bn:  # BatchNorm1d buffers at torch's initial values (use_bn_in_head: dino.py:66-72)
+        import torch
+        for h in ("head.", "momentum_head."):
+            for bn in ("mlp.1.", "mlp.4."):
+                sd[h + bn + "running_mean"] = torch.zeros(hidden)
+                sd[h + bn + "running_var"] = torch.ones(hidden)
+                sd[h + bn + "num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
     sd.update(P.fill_state_dict({"classifier.weight": (7, D), "classifier.bias": (7,),
                                  "dino_loss_func.center": (1, PR)}, seed=seeds[4]))
     return sd
 
 
 def golden_step(name, D, PR, nch, sizes, n_large, epoch, clip_grad=0.0, lr=5e-4, wd=1e-4, base_tau=0.9995,
-                max_steps=100):
+                max_steps=100, use_bn=False):
     cfg = refshim.dino_cfg(embed_dim=D, num_prototypes=PR, num_large_crops=n_large,
                            num_small_crops=len(sizes) - n_large, clip_grad=clip_grad, lr=lr, weight_decay=wd,
-                           base_tau=base_tau)
+                           base_tau=base_tau, use_bn_in_head=use_bn)
     model = ref.DINO(cfg)
-    sd = build_sd(D, PR)
+    sd = build_sd(D, PR, use_bn=use_bn)
     model.load_state_dict(sd)
     imgs = P.make_images(nch, sizes, seed=7)
     batch = ref.one_channel_collate_fn([(i, c, l) for i, (c, l) in enumerate(imgs)])
@@ -127,11 +134,17 @@ def golden_step(name, D, PR, nch, sizes, n_large, epoch, clip_grad=0.0, lr=5e-4,
            "loss": np.float64(loss.item()), "grad_names": np.asarray(names), "grad_norms": np.asarray(gnorms),
            "none_grad_names": np.asarray(none_names),
            "center_new": f32(model.dino_loss_func.center)[0, :256],
-           "center_new_sum": np.float64(model.dino_loss_func.center.double().sum().item())}
+           "center_new_sum": np.float64(model.dino_loss_func.center.double().sum().item()), "use_bn": int(use_bn)}
+    if use_bn:  # the heads' BatchNorm running estimates after the step's forward passes (one update per global crop), and two BN gradients
+        for n, b in model.named_buffers():
+            if n.startswith(("head.", "momentum_head.")) and b.is_floating_point():
+                out["bn::" + n] = f32(b)
+        for n in ("head.mlp.1.weight", "head.mlp.4.bias"):
+            out["grad::" + n] = f32(dict(model.named_parameters())[n].grad)
     # a few full gradient tensors (small ones) for element-wise checks
     for n in ("backbone.cls_token", "backbone.channel_token", "backbone.norm.weight", "backbone.blocks.0.norm1.weight",
               "backbone.blocks.11.norm1.bias", "backbone.blocks.5.self_attn.in_proj_bias",
-              "backbone.token_learner.proj.bias", "head.mlp.4.bias"):
+              "backbone.token_learner.proj.bias", "head.mlp.6.bias" if use_bn else "head.mlp.4.bias"):
         out["grad::" + n] = f32(dict(model.named_parameters())[n].grad)
     pe = dict(model.named_parameters())["backbone.pos_embed"].grad
     out["grad::backbone.pos_embed[:8]"] = f32(pe[0, 0, :8])
@@ -352,6 +365,10 @@ if __name__ == "__main__":
             golden_step("step_base_c10", 768, 4096, [10, 3], [224, 224], 2, 1)
         if "big" in which:
             golden_step("step_tiny_fused_rows", 192, 4096, [10, 10, 10, 10, 10, 8, 5, 3, 1], [224, 224, 96, 96], 2, 1)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "steps_r03":
+        # round 3: BatchNorm in the head (method_kwargs.use_bn_in_head = True, src/methods/dino.py:59-77)
+        golden_step("step_tiny_bn_head", 192, 4096, [1, 2, 1, 3, 1, 2, 1, 1, 2, 1, 1, 1, 2, 1, 3, 1], [224, 224, 96], 2, 1, use_bn=True)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "attnmap":
         golden_attnmap("attnmap_tiny", 192, 2, 224, 51, 52)

@@ -2,12 +2,19 @@
 from oracle import procedural as P
 
 
-def build_sd(D, PR, seeds=(1, 2, 3, 4, 5), hidden=2048, bott=256):
+def build_sd(D, PR, seeds=(1, 2, 3, 4, 5), hidden=2048, bott=256, use_bn=False):
     sd = {}
     sd.update({"backbone." + k: v for k, v in P.fill_state_dict(P.backbone_shapes(D), seed=seeds[0]).items()})
     sd.update({"momentum_backbone." + k: v for k, v in P.fill_state_dict(P.backbone_shapes(D), seed=seeds[1]).items()})
-    sd.update({"head." + k: v for k, v in P.fill_state_dict(P.head_shapes(D, hidden, bott, PR), seed=seeds[2]).items()})
-    sd.update({"momentum_head." + k: v for k, v in P.fill_state_dict(P.head_shapes(D, hidden, bott, PR), seed=seeds[3]).items()})
+    sd.update({"head." + k: v for k, v in P.fill_state_dict(P.head_shapes(D, hidden, bott, PR, use_bn=use_bn), seed=seeds[2]).items()})
+    sd.update({"momentum_head." + k: v for k, v in P.fill_state_dict(P.head_shapes(D, hidden, bott, PR, use_bn=use_bn), seed=seeds[3]).items()})
+    if use_bn:  # BatchNorm1d buffers at torch's initial values (use_bn_in_head: dino.py:66-72)
+        import torch
+        for h in ("head.", "momentum_head."):
+            for bn in ("mlp.1.", "mlp.4."):
+                sd[h + bn + "running_mean"] = torch.zeros(hidden)
+                sd[h + bn + "running_var"] = torch.ones(hidden)
+                sd[h + bn + "num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
     sd.update(P.fill_state_dict({"classifier.weight": (7, D), "classifier.bias": (7,),
                                  "dino_loss_func.center": (1, PR)}, seed=seeds[4]))
     return sd

@@ -1091,3 +1091,36 @@ def test_row_wise_kernels_at_bench_rows_equal_their_small_runs(D, M):
     ref = torch.zeros_like(big)
     ref[rows.long()] = g
     assert torch.equal(sc, ref)
+
+@pytest.mark.parametrize("N,f32in", [(4, True), (64, True), (1000, False), (5120, True)])
+def test_batchnorm_kernels_match_torch(N, f32in):
+    """BatchNorm1d of the head's projector (use_bn_in_head; reference src/methods/dino.py:59-77): statistics, running estimates,
+    normalise + affine + GELU, and the backward, against torch.nn.functional.batch_norm in fp32 on the same inputs."""
+    from chadavit_amd import ops
+    dev = _dev()
+    C = 2048
+    z = _rand((N, C), 401, 1.5).to(dev) + _rand((C,), 402, 2.0).to(dev)
+    if not f32in:
+        z = z.bfloat16()
+    zf = z.float()
+    ga, be = (1 + _rand((C,), 403, 0.3)).to(dev), _rand((C,), 404, 0.3).to(dev)
+    rm, rv = _rand((C,), 405, 0.1).to(dev), (1 + _rand((C,), 406, 0.1)).to(dev)
+    rm_t, rv_t = rm.clone(), rv.clone()
+    mean, rstd = ops.bn_stats(z, 1e-5, rm, rv, 0.1)
+    ref = torch.nn.functional.batch_norm(zf, rm_t, rv_t, ga, be, True, 0.1, 1e-5)
+    assert torch.allclose(mean, zf.mean(0), atol=2e-6, rtol=1e-5)
+    assert torch.allclose(rstd, (zf.var(0, unbiased=False) + 1e-5).rsqrt(), rtol=2e-4)
+    assert torch.allclose(rm, rm_t, atol=1e-6, rtol=1e-5) and torch.allclose(rv, rv_t, atol=1e-6, rtol=2e-4)
+    pre, act = ops.bn_apply_gelu(z, mean, rstd, ga, be)
+    _close(pre, ref, 1e-2, 1e-2, "bn output")
+    _close(act, torch.nn.functional.gelu(pre.float()), 1e-2, 1e-2, "gelu")
+    dy = _rand((N, C), 407, 1.0).bfloat16().to(dev)
+    zr, gar, ber = zf.clone().requires_grad_(True), ga.clone().requires_grad_(True), be.clone().requires_grad_(True)
+    torch.nn.functional.batch_norm(zr, None, None, gar, ber, True, 0.1, 1e-5).backward(dy.float())
+    dga, dbe = torch.full((C,), 3.0, device=dev), torch.full((C,), -2.0, device=dev)
+    dz = ops.bn_bwd(dy, z, mean, rstd, ga, dga, dbe, accumulate=False)
+    assert float((dz.float() - zr.grad).norm() / zr.grad.norm()) <= 5e-3
+    assert torch.allclose(dga, gar.grad, rtol=1e-3, atol=1e-3 * float(gar.grad.abs().max()))
+    assert torch.allclose(dbe, ber.grad, rtol=1e-3, atol=1e-3 * float(ber.grad.abs().max()))
+    ops.bn_bwd(dy, z, mean, rstd, ga, dga, dbe, accumulate=True)
+    assert torch.allclose(dga, 2 * gar.grad, rtol=1e-3, atol=2e-3 * float(gar.grad.abs().max()))

@@ -91,7 +91,7 @@ def test_schedules_match_reference():
 def _step_case(g):
     from tests.golden_util import build_sd
     D, PR = int(g["D"]), int(g["P"])
-    sd = build_sd(D, PR)
+    sd = build_sd(D, PR, use_bn=bool(int(g["use_bn"])) if "use_bn" in g.files else False)
     imgs = P.make_images([int(c) for c in g["nch"]], [int(s) for s in g["sizes"]], seed=7)
     crops, _, ncl = R.collate(imgs)
     return sd, crops, ncl
@@ -119,7 +119,7 @@ def test_validation_step_matches_reference():
     assert o["batch_size"] == int(g["plain::batch_size"])
 
 
-_STEP_GOLDENS = ["step_tiny_multicrop", "step_tiny_c1_clip", "step_small_mixed", "step_base_c10"]
+_STEP_GOLDENS = ["step_tiny_multicrop", "step_tiny_c1_clip", "step_small_mixed", "step_base_c10", "step_tiny_bn_head"]
 if os.environ.get("CHADAVIT_SLOW_TESTS"):  # 26282-row Tiny step: 85 s of oracle on 8 cores (checked when the golden was made)
     _STEP_GOLDENS.append("step_tiny_fused_rows")
 
@@ -135,17 +135,26 @@ def test_training_step_matches_reference(name):
     for n, gn in zip(g["grad_names"], g["grad_norms"]):
         n = str(n)
         assert grads[n] is not None, n
-        assert abs(grads[n].double().norm().item() - gn) <= 2e-4 * gn + 1e-9, n
+        # (BatchNorm right behind the head's first Linear cancels any per-column shift of the features: backbone.norm.bias gets a
+        #  gradient that is zero up to rounding, ~1e-7, in the reference and here)
+        assert abs(grads[n].double().norm().item() - gn) <= 2e-4 * gn + (1e-7 if "use_bn" in g.files and int(g["use_bn"]) else 1e-9), n
     for n in none_names:
         if n.startswith("classifier."):
             continue
         assert grads[n] is None, n
     for key in g.files:
         if key.startswith("grad::") and not key.endswith("]"):
-            np.testing.assert_allclose(grads[key[6:]].numpy(), g[key], rtol=2e-3, atol=1e-7)
+            np.testing.assert_allclose(grads[key[6:]].numpy(), g[key], rtol=2e-3, atol=3e-6 if "use_bn" in g.files and int(g["use_bn"]) else 1e-7)
     np.testing.assert_allclose(newc[0, :256].numpy(), g["center_new"], atol=1e-7, rtol=0)
+    for key in g.files:   # use_bn_in_head: the heads' BatchNorm running estimates after one update per global crop
+        if key.startswith("bn::"):
+            which, rest = key[4:].split(".", 1)
+            np.testing.assert_allclose(aux[which + "_bn"][rest].numpy(), g[key], rtol=1e-5, atol=1e-6)
     # AdamW + EMA (base.py:1263-1273, momentum.py:63-87)
     lr, wd, tau = float(g["lr"]), float(g["wd"]), float(g["tau_used"])
+    # (with BatchNorm in the head a handful of backbone gradient entries are zero up to rounding, and AdamW's first step moves a
+    #  parameter by lr * sign(gradient): allow a few dozen such entries to land on the other side)
+    flips = 60 * lr if "use_bn" in g.files and int(g["use_bn"]) else 0.0
     post = dict(zip([str(n) for n in g["post_names"]], g["post_sums"]))
     new_student = {}
     for n, gr in grads.items():
@@ -155,12 +164,16 @@ def test_training_step_matches_reference(name):
             continue
         new_student[n], _, _ = R.adamw_step(p, gr, torch.zeros_like(p), torch.zeros_like(p), 1, lr, wd)
     for n in ["backbone.norm.weight"]:
-        np.testing.assert_allclose(new_student[n].numpy(), g["post::" + n], atol=1e-6, rtol=0)
+        d = np.abs(new_student[n].numpy() - g["post::" + n])
+        if flips:   # (an entry whose gradient is noise may move by lr in the other direction)
+            assert (d > 1e-6).sum() <= 3 and d.max() <= 2.1 * lr, (d.max(), (d > 1e-6).sum())
+        else:
+            np.testing.assert_allclose(new_student[n].numpy(), g["post::" + n], atol=1e-6, rtol=0)
     for n, v in new_student.items():
-        assert abs(v.double().sum().item() - post[n]) <= 1e-5 * (abs(post[n]) + v.numel() ** 0.5), n
+        assert abs(v.double().sum().item() - post[n]) <= 1e-5 * (abs(post[n]) + v.numel() ** 0.5) + flips, n
         tn = n.replace("backbone.", "momentum_backbone.", 1) if n.startswith("backbone.") else n.replace("head.", "momentum_head.", 1)
         tv = tau * sd[tn] + (1 - tau) * v
-        assert abs(tv.double().sum().item() - post[tn]) <= 1e-5 * (abs(post[tn]) + v.numel() ** 0.5), tn
+        assert abs(tv.double().sum().item() - post[tn]) <= 1e-5 * (abs(post[tn]) + v.numel() ** 0.5) + flips, tn
     assert abs(R.tau_schedule(1, int(g["max_steps"]), float(g["base_tau"]), 1.0) - float(g["tau_next"])) < 1e-12
 
 
