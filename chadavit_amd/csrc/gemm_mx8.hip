@@ -318,7 +318,7 @@ __global__ __launch_bounds__((MX_NCONS + MX_NPROD) * 64, 3) void gemm_mx8_kernel
           } else {
             o = __builtin_bit_cast(bf16x8, u32x4{qq[0], qq[1], qq[2], qq[3]});
           }
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), out_rs, out_voff, (mt * 16 + 8 * k) * a.ldo * 2, MX_ST_AUX);
+          if (a.Out) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), out_rs, out_voff, (mt * 16 + 8 * k) * a.ldo * 2, MX_ST_AUX);
           if (a.OutQ) {  // (uniform) quantise the bf16 values: a 32-column MX block is the four lanes g = 0..3 of one (r & 7, r3)
             float f[8], amax = 0.f;
 #pragma unroll
