@@ -1,4 +1,5 @@
-"""Lightning-free training loop that calls the DINO hooks in Lightning's order:
+"""Lightning-free training loop that calls the DINO hooks in Lightning's order (a hook the module does not
+define -- LinearModel has no EMA / gradient hooks -- is skipped, as Lightning's no-op defaults would be):
 
   on_train_start; per epoch: on_train_epoch_start; per batch: training_step -> loss.backward() ->
   [gradient all-reduce finishes] -> on_after_backward -> optimizer.step() -> optimizer_zero_grad ->
@@ -33,32 +34,40 @@ class Trainer:
         conf = model.configure_optimizers()
         if isinstance(conf, tuple) or isinstance(conf, list):
             self.optimizer = conf[0][0]
-            self.scheduler = conf[1][0]["scheduler"]
+            sched = conf[1][0]
+            self.scheduler = sched["scheduler"] if isinstance(sched, dict) else sched
         else:
             self.optimizer = conf
         if self.grad_sync is not None:
             self.grad_sync.attach(model)
-        model.on_train_start()
+        self._hook("on_train_start")
         return self
+
+    def _hook(self, name, *args):
+        fn = getattr(self.model, name, None)
+        return fn(*args) if callable(fn) else None
 
     def train_step(self, batch, batch_idx: int = 0) -> torch.Tensor:
         m = self.model
         m.current_epoch = self.current_epoch
         if batch_idx == 0:
-            m.on_train_epoch_start()
+            self._hook("on_train_epoch_start")
         loss = m.training_step(batch, batch_idx)
         if self.grad_sync is not None:
             self.grad_sync.begin_backward()
         loss.backward()
         if self.grad_sync is not None:
             self.grad_sync.finish()
-        m.on_after_backward()
+        self._hook("on_after_backward")
         self.optimizer.step()
         self.global_step += 1
-        m.optimizer_zero_grad(self.current_epoch, batch_idx, self.optimizer)
+        if callable(getattr(m, "optimizer_zero_grad", None)):
+            m.optimizer_zero_grad(self.current_epoch, batch_idx, self.optimizer)
+        else:
+            self.optimizer.zero_grad(set_to_none=True)
         if self.scheduler is not None:
             self.scheduler.step()
-        m.on_train_batch_end(None, batch, batch_idx)
+        self._hook("on_train_batch_end", None, batch, batch_idx)
         return loss
 
     def fit(self, model, batches_per_epoch: Iterable):

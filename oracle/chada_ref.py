@@ -421,6 +421,56 @@ def adamw_step(param: torch.Tensor, grad: torch.Tensor, m: torch.Tensor, v: torc
 
 
 # ======================================================================================
+# (f)-3b  linear / fine-tune evaluation  (src/methods/linear.py:373-511; src/utils/metrics.py:26-52)
+# ======================================================================================
+def accuracy_at_k(outputs: torch.Tensor, targets: torch.Tensor, top_k=(1, 5)) -> List[float]:
+    """Percent of rows whose target is among the k largest outputs (metrics.py:26-52)."""
+    pred = outputs.topk(min(max(top_k), outputs.shape[1]), 1, True, True)[1]
+    hit = pred.eq(targets.view(-1, 1))
+    return [100.0 * float(hit[:, :k].any(1).sum()) / targets.numel() for k in top_k]
+
+
+def linear_features(bb: Params, x: torch.Tensor, num_channels: Sequence[int], return_all_tokens: bool, mixed_channels: bool,
+                    nheads: int = 2) -> torch.Tensor:
+    """LinearModel.forward up to the classifier input (linear.py:383-427, multi_channels branch): CLS rows (B, D), or -- all
+    tokens, fixed channel count -- the valid patch tokens viewed per channel image, grouped per image and flattened."""
+    f = backbone_ragged(bb, x, num_channels, nheads, return_all_tokens=return_all_tokens)
+    if not mixed_channels and return_all_tokens:
+        chunks = f.view(sum(num_channels), -1, f.shape[-1])                       # :410-413
+        f = torch.stack(torch.split(chunks, list(num_channels), dim=0), dim=0)     # :414-421 (equal channel counts or it fails)
+        f = f.flatten(start_dim=1)                                                 # :423
+    return f
+
+
+def linear_step(bb: Params, W: torch.Tensor, b: torch.Tensor, x: torch.Tensor, num_channels: Sequence[int], targets: torch.Tensor,
+                return_all_tokens: bool, mixed_channels: bool, finetune: bool, nheads: int = 2):
+    """shared_step (linear.py:434-511) + backward: returns (loss, logits, feats, acc1, acc5, grads) where grads holds
+    "classifier.weight", "classifier.bias" and, when fine-tuning, "backbone.<name>" for every backbone tensor that gets one."""
+    bbp = {k: v.detach().clone().requires_grad_(finetune) for k, v in bb.items()}
+    Wp, bp = W.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+    with torch.set_grad_enabled(finetune):                                         # :380
+        feats = linear_features(bbp, x, num_channels, return_all_tokens, mixed_channels, nheads)
+    logits = feats @ Wp.t() + bp                                                   # :429-431
+    loss = F.cross_entropy(logits, targets)                                        # :466
+    loss.backward()
+    acc1, acc5 = accuracy_at_k(logits.detach(), targets)
+    grads = {"classifier.weight": Wp.grad, "classifier.bias": bp.grad}
+    if finetune:
+        grads.update({"backbone." + k: v.grad for k, v in bbp.items() if v.grad is not None})
+    return loss.detach(), logits.detach(), feats.detach(), acc1, acc5, grads
+
+
+def sgd_step(param: torch.Tensor, grad: torch.Tensor, buf: Optional[torch.Tensor], lr: float, momentum: float = 0.0,
+             weight_decay: float = 0.0):
+    """torch.optim.SGD single-tensor update (linear.py:51-56 "sgd"; dampening 0, no Nesterov)."""
+    d_p = grad + weight_decay * param
+    if momentum != 0:
+        buf = d_p.clone() if buf is None else buf * momentum + d_p
+        d_p = buf
+    return param - lr * d_p, buf
+
+
+# ======================================================================================
 # (f)-1  LARS  (src/utils/lars.py:112-167)  and the bias/norm weight-decay split (src/utils/misc.py:425-454)
 # ======================================================================================
 def lars_step(param: torch.Tensor, grad: torch.Tensor, buf: Optional[torch.Tensor], lr: float, momentum: float = 0.9,

@@ -173,6 +173,55 @@ def load():
     return ns
 
 
+def load_linear():
+    """The reference's linear / fine-tune evaluation module (src/methods/linear.py), for the golden vectors of
+    chadavit_amd.methods.linear.  Third-party names it imports and this image lacks are stubbed: wandb, seaborn,
+    pytorch_lightning.loggers.WandbLogger, and the torchmetrics.classification metric classes (stand-ins that return 0 -- the
+    goldens hold only what the reference computes itself: logits, F.cross_entropy, accuracy_at_k, gradients); the SLURM logger
+    module (lightning_fabric imports) is replaced by an empty class, it is only named in an isinstance at epoch end."""
+    ns = load()
+    import torch
+
+    class _ZeroMetric(nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+
+        def forward(self, *a, **k):
+            return torch.zeros(())
+    for name in ("wandb", "seaborn"):
+        if name not in sys.modules:
+            _stub(name)
+    pl = sys.modules["pytorch_lightning"]
+    if "pytorch_lightning.loggers" not in sys.modules:
+        pl.loggers = _stub("pytorch_lightning.loggers", WandbLogger=type("WandbLogger", (), {}))
+    tm = sys.modules["torchmetrics"]
+    if "torchmetrics.classification" not in sys.modules:
+        tm.classification = _stub("torchmetrics.classification", **{n: _ZeroMetric for n in (
+            "MulticlassAccuracy", "MulticlassRecall", "MulticlassPrecision", "MulticlassAUROC", "MulticlassF1Score",
+            "MulticlassConfusionMatrix")})
+    if "src.utils.slurm_logger" not in sys.modules:
+        _stub("src.utils.slurm_logger", SLURMLogger=type("SLURMLogger", (), {}))
+    if "src.methods.linear" not in sys.modules:
+        _load("src.methods.linear", "src/methods/linear.py")
+    ns.LinearModel = sys.modules["src.methods.linear"].LinearModel
+    return ns
+
+
+def linear_cfg(embed_dim=192, return_all_tokens=False, img_channels=3, mixed_channels=False, num_classes=7, finetune=False,
+               optimizer="sgd", lr=0.1, weight_decay=0.0, scheduler="none", max_epochs=10, batch_size=4):
+    """Minimal cfg for the reference `LinearModel(backbone, cfg)` (linear.py:65-232 reads these keys)."""
+    return _AttrDict({
+        "backbone": {"name": "vit_channels",
+                     "kwargs": {"embed_dim": embed_dim, "patch_size": 16, "return_all_tokens": return_all_tokens,
+                                "max_number_channels": 10}},
+        "data": {"dataset": "synthetic", "num_classes": num_classes, "img_channels": img_channels, "max_img_channels": 10},
+        "channels_strategy": "multi_channels", "mixed_channels": mixed_channels, "max_epochs": max_epochs,
+        "finetune": finetune,
+        "optimizer": {"name": optimizer, "batch_size": batch_size, "lr": lr, "weight_decay": weight_decay},
+        "scheduler": {"name": scheduler}, "slurm": {"enabled": False}, "wandb": {"enabled": False},
+    })
+
+
 def load_custom_transforms():
     """The reference's own augmentation arithmetic (src/data/custom_transforms.py), for golden vectors of CustomColorJitter.
     Its third-party imports are absent here and only provide base classes / names at import time: albumentations

@@ -342,6 +342,65 @@ def golden_val(name, D, PR, nch, sizes, n_large):
     print("wrote", name, out["ssl::dino_loss_val"])
 
 
+def golden_linear(name, D, nch, S, return_all_tokens, finetune, n_cls=7, lr=0.1, momentum=0.9, wd=1e-4):
+    """Reference LinearModel (src/methods/linear.py): one training step (shared_step + backward + torch SGD as
+    configure_optimizers builds it with scheduler "none") and one validation step on a second batch."""
+    nsl = refshim.load_linear()
+    mixed = len(set(nch)) > 1
+    cfg = refshim.linear_cfg(embed_dim=D, return_all_tokens=return_all_tokens, img_channels=nch[0], mixed_channels=mixed,
+                             num_classes=n_cls, finetune=finetune, lr=lr, weight_decay=wd)
+    bb = ref.vit_channels("dino", patch_size=16, embed_dim=D, return_all_tokens=return_all_tokens, max_number_channels=10)
+    bb.load_state_dict(P.fill_state_dict(P.backbone_shapes(D), seed=1))
+    model = nsl.LinearModel(bb, cfg)
+    K = model.classifier.in_features
+    model.classifier.load_state_dict(P.fill_state_dict({"weight": (n_cls, K), "bias": (n_cls,)}, seed=21))
+    out = {"D": D, "nch": np.asarray(nch), "S": S, "return_all_tokens": int(return_all_tokens), "finetune": int(finetune),
+           "n_cls": n_cls, "K": K, "lr": lr, "momentum": momentum, "wd": wd, "mixed": int(mixed)}
+    imgs = P.make_images(nch, [S], seed=9)
+    batch = ref.one_channel_collate_fn([(i, c, l) for i, (c, l) in enumerate(imgs)])
+    model.train()
+    opt = torch.optim.SGD(model.classifier.parameters() if not finetune else
+                          [{"name": "backbone", "params": model.backbone.parameters()},
+                           {"name": "classifier", "params": model.classifier.parameters()}],
+                          lr=lr, weight_decay=wd, momentum=momentum)
+    met = model.shared_step(batch, 0, 0)
+    loss = met["loss"]
+    loss.backward()
+    with torch.no_grad():
+        fw = model(batch[0], 0)
+    out.update({"loss": np.float64(loss.item()), "acc1": f32(met["acc1"]), "acc5": f32(met["acc5"]), "batch_size": int(met["batch_size"]),
+                "logits": f32(fw["logits"]), "feats_shape": np.asarray(fw["feats"].shape),
+                "feats_sum": np.float64(fw["feats"].double().sum().item()), "feats_head": f32(fw["feats"][:, :64]),
+                "targets": batch[1].numpy(),
+                "dW_norm": np.float64(model.classifier.weight.grad.double().norm().item()),
+                "dW_head": f32(model.classifier.weight.grad[:, :64]), "db": f32(model.classifier.bias.grad)})
+    if finetune:
+        names, gn = [], []
+        for n, p in model.backbone.named_parameters():
+            if p.grad is not None:
+                names.append(n)
+                gn.append(p.grad.double().norm().item())
+        out["bb_grad_names"], out["bb_grad_norms"] = np.asarray(names), np.asarray(gn)
+        out["grad::norm.weight"] = f32(model.backbone.norm.weight.grad)
+        out["grad::cls_token"] = f32(model.backbone.cls_token.grad)
+    opt.step()
+    out["post_W_head"] = f32(model.classifier.weight[:, :64])
+    out["post_b"] = f32(model.classifier.bias)
+    out["post_W_sum"] = np.float64(model.classifier.weight.double().sum().item())
+    if finetune:
+        out["post::norm.weight"] = f32(model.backbone.norm.weight)
+    # validation on another batch with the updated weights
+    model.eval()
+    imgs2 = P.make_images(nch, [S], seed=10)
+    batch2 = ref.one_channel_collate_fn([(i, c, l) for i, (c, l) in enumerate(imgs2)])
+    with torch.no_grad():
+        v = model.validation_step(batch2, 0)
+    out.update({"val_loss": np.float64(v["val_loss"].item()), "val_acc1": f32(v["val_acc1"]), "val_acc5": f32(v["val_acc5"]),
+                "val_batch_size": int(v["batch_size"])})
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, "loss", loss.item(), "val", v["val_loss"].item())
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "val":
         golden_val("val_tiny", 192, 4096, [2, 1, 4], [224, 224, 96], 2)
@@ -369,6 +428,12 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "steps_r03":
         # round 3: BatchNorm in the head (method_kwargs.use_bn_in_head = True, src/methods/dino.py:59-77)
         golden_step("step_tiny_bn_head", 192, 4096, [1, 2, 1, 3, 1, 2, 1, 1, 2, 1, 1, 1, 2, 1, 3, 1], [224, 224, 96], 2, 1, use_bn=True)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "linear":
+        # round 3: linear / fine-tune evaluation (src/methods/linear.py) on CLS features (mixed channel counts, frozen backbone)
+        # and on all patch tokens flattened per image (two channels each, fine-tuning the backbone)
+        golden_linear("linear_tiny_cls", 192, [3, 1, 2, 5, 1, 4], 224, False, False)
+        golden_linear("linear_tiny_all_tokens_finetune", 192, [2, 2, 2, 2], 224, True, True, lr=2e-4)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "attnmap":
         golden_attnmap("attnmap_tiny", 192, 2, 224, 51, 52)

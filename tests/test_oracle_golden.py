@@ -249,3 +249,59 @@ def test_custom_color_jitter_matches_reference():
         out = R.custom_color_jitter(img, g[f"shifts{k}"], g[f"gammas{k}"])
         np.testing.assert_allclose(out, g[f"out{k}"], atol=1e-6)
         assert out.min() >= 0.0 and out.max() <= 1.0
+
+
+def _linear_case(g, seed_x):
+    D, S = int(g["D"]), int(g["S"])
+    nch = [int(c) for c in g["nch"]]
+    bb = P.fill_state_dict(P.backbone_shapes(D), seed=1)
+    cl = P.fill_state_dict({"weight": (int(g["n_cls"]), int(g["K"])), "bias": (int(g["n_cls"]),)}, seed=21)
+    imgs = P.make_images(nch, [S], seed=seed_x)
+    x, labels, ncl = R.collate(imgs)
+    return bb, cl["weight"], cl["bias"], x, labels, ncl[0], nch
+
+
+@pytest.mark.parametrize("name", ["linear_tiny_cls", "linear_tiny_all_tokens_finetune"])
+def test_linear_eval_step_matches_reference(name):
+    """The oracle's restatement of LinearModel.shared_step + backward + one SGD step + a validation step, against the reference
+    (src/methods/linear.py run through oracle/refshim.load_linear by tests/golden/make_golden.py linear)."""
+    g = _load(name)
+    rat, ft, mixed = bool(g["return_all_tokens"]), bool(g["finetune"]), bool(g["mixed"])
+    bb, W, b, x, labels, nch, _ = _linear_case(g, 9)
+    assert [int(t) for t in g["targets"]] == [int(t) for t in labels]
+    loss, logits, feats, acc1, acc5, grads = R.linear_step(bb, W, b, x, nch, labels, rat, mixed, ft)
+    assert list(feats.shape) == [int(v) for v in g["feats_shape"]]
+    assert int(g["batch_size"]) == x.shape[0]          # channel images, not images (linear.py:454)
+    np.testing.assert_allclose(logits.numpy(), g["logits"], atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(feats[:, :64].numpy(), g["feats_head"], atol=1e-5, rtol=1e-5)
+    assert abs(float(feats.double().sum()) - float(g["feats_sum"])) <= 1e-5 * max(1.0, abs(float(g["feats_sum"]))) + 1e-2
+    assert abs(float(loss) - float(g["loss"])) <= 1e-6 * 10
+    assert acc1 == pytest.approx(float(g["acc1"][0])) and acc5 == pytest.approx(float(g["acc5"][0]))
+    np.testing.assert_allclose(grads["classifier.weight"][:, :64].numpy(), g["dW_head"], atol=1e-6, rtol=1e-4)
+    np.testing.assert_allclose(grads["classifier.bias"].numpy(), g["db"], atol=1e-6, rtol=1e-4)
+    assert float(grads["classifier.weight"].double().norm()) == pytest.approx(float(g["dW_norm"]), rel=1e-4)
+    lr, mom, wd = float(g["lr"]), float(g["momentum"]), float(g["wd"])
+    W1, _ = R.sgd_step(W, grads["classifier.weight"], None, lr, mom, wd)
+    b1, _ = R.sgd_step(b, grads["classifier.bias"], None, lr, mom, wd)
+    np.testing.assert_allclose(W1[:, :64].numpy(), g["post_W_head"], atol=1e-6, rtol=1e-5)
+    np.testing.assert_allclose(b1.numpy(), g["post_b"], atol=1e-6, rtol=1e-5)
+    bb1 = dict(bb)
+    if ft:
+        for n, gn in zip(g["bb_grad_names"], g["bb_grad_norms"]):
+            got = float(grads["backbone." + str(n)].double().norm())
+            assert abs(got - float(gn)) <= 1e-3 * float(gn) + 1e-6, (n, got, float(gn))
+        np.testing.assert_allclose(grads["backbone.norm.weight"].numpy(), g["grad::norm.weight"], atol=2e-5, rtol=1e-3)
+        for k in bb:
+            if "backbone." + k in grads:
+                bb1[k], _ = R.sgd_step(bb[k], grads["backbone." + k], None, lr, mom, wd)
+        np.testing.assert_allclose(bb1["norm.weight"].numpy(), g["post::norm.weight"], atol=1e-6, rtol=1e-5)
+    # validation step on the second batch with the updated weights
+    _, _, _, x2, labels2, nch2, _ = _linear_case(g, 10)
+    with torch.no_grad():
+        f2 = R.linear_features(bb1, x2, nch2, rat, mixed)
+        lg2 = f2 @ W1.t() + b1
+    vloss = float(torch.nn.functional.cross_entropy(lg2, labels2))
+    assert abs(vloss - float(g["val_loss"])) <= 2e-4 * max(1.0, float(g["val_loss"]))
+    a1, a5 = R.accuracy_at_k(lg2, labels2)
+    assert a1 == pytest.approx(float(g["val_acc1"][0])) and a5 == pytest.approx(float(g["val_acc5"][0]))
+    assert int(g["val_batch_size"]) == x2.shape[0]
