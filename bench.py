@@ -50,8 +50,8 @@ WORKLOADS = {
     "cfg3": dict(desc="ChAda-ViT-Small/16, variable 1-10 channel, DINO 2 global + 8 local crops", D=384, channels="1-10",
                  n_global=2, n_local=8, P=4096, batch=128),
     "cfg5": dict(desc="ChAda-ViT-Base/16, 10-channel 224x224 (max-token stress), DINO 2 global + 8 local crops, fp8 weight path "
-                      "(encoder nn.Linear forwards on the MX-scaled fp8 MFMA: OCP-MX e4m3 weights and input activations, fp32 "
-                      "accumulate; attention / LayerNorm / backward bf16)", D=768, channels="10", n_global=2, n_local=8,
+                      "(encoder nn.Linear forwards and the FFN's two dX GEMMs on the MX-scaled fp8 MFMA: OCP-MX e4m3 operands, fp32 "
+                      "accumulate; attention / LayerNorm / weight gradients / the other dX GEMMs bf16)", D=768, channels="10", n_global=2, n_local=8,
                  P=4096, batch=32, weight_dtype="fp8"),
     "cfg5-bf16": dict(desc="ChAda-ViT-Base/16, 10-channel 224x224, DINO 2 global + 8 local crops, bf16 weights (comparison run for "
                            "cfg5)", D=768, channels="10", n_global=2, n_local=8, P=4096, batch=32),
@@ -327,7 +327,7 @@ def replay_launches(counts, nch, wl, dev, reps=10):
             xs_ = torch.full((K // 32, (M + 3) // 4 * 4), 120, device=dev, dtype=torch.uint8)[:, :M]
             ws_ = torch.full((K // 32, (N + 3) // 4 * 4), 120, device=dev, dtype=torch.uint8)[:, :N]
             bias = torch.zeros(N, device=dev)
-            aux = torch.randn((M, N), device=dev).to(bf) if epi == 3 else None
+            aux = torch.randn((M, N), device=dev).to(bf) if epi in (3, 4) else None
             o = torch.empty((M, N), device=dev, dtype=bf)
             fn = lambda: ops.gemm_nt_mx8(xq, xs_, wq, ws_, bias=bias, epilogue=epi, aux=aux, out=o)
         elif name == "ffn_fwd":
@@ -634,7 +634,7 @@ def other_workload_leg(name, args, dev, steps=3, warmup=2, graph=False):
         step_fn.close()
     res = {"workload": wl["desc"], "images_per_gpu": wl["batch"], "images_per_s": round(wl["batch"] * steps / dt, 2),
            "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps, "warmup": warmup, "final_loss": round(float(last.item()), 4),
-           "dtype": "fp8-weights (MX e4m3 x e4m3 forward GEMMs; bf16 elsewhere)" if wl.get("weight_dtype") == "fp8" else "bf16",
+           "dtype": "fp8-weights (MX e4m3 x e4m3 forward GEMMs and the FFN's two dX GEMMs; bf16 elsewhere)" if wl.get("weight_dtype") == "fp8" else "bf16",
            "launch": "one hipGraph per step (GraphedTrainStep)" if graph else "eager"}
     chans = list(range(1, 11)) if "-" in wl["channels"] else [int(wl["channels"])]
     gf_exec = gflop_per_image(chans, wl["D"], wl["P"], wl["n_global"], wl["n_local"], cls_last=bool(model.backbone.cls_only_last_block))
@@ -863,7 +863,7 @@ def main():
             "metric": "images/sec ChAda-ViT DINO multi-crop pretrain (whole training step)",
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "fp8-weights (MX e4m3 x e4m3 forward GEMMs, fp32 accumulate; bf16 elsewhere)" if wl.get("weight_dtype") == "fp8" else "bf16",
+            "dtype": "fp8-weights (MX e4m3 x e4m3 forward GEMMs and the FFN's two dX GEMMs, fp32 accumulate; bf16 elsewhere)" if wl.get("weight_dtype") == "fp8" else "bf16",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {wl['desc']}, bf16 storage / fp32 accumulate, {B} images per GPU, "
                                    f"head 2048/256/{wl['P']}, AdamW, reference-parity crop semantics",

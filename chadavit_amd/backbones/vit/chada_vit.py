@@ -116,7 +116,7 @@ class ChAdaViT(nn.Module):
         self.fused_ln_pair = True
         # "bf16" (default) or "fp8": the block's four nn.Linear forwards (in_proj, out_proj, linear1, linear2) on the MX-scaled fp8
         # MFMA -- weights AND their input activations quantised to OCP-MX e4m3 (BASELINE.json configs[4], ChAda-ViT-Base); the
-        # backward keeps bf16 operands.  Needs embed_dim % 128 == 0.
+        # backward keeps bf16 operands except the FFN's dX GEMMs (fp8_dx below).  Needs embed_dim % 128 == 0.
         self.weight_dtype = "bf16"
         # return_all_tokens = False: only norm(x)[:, 0] leaves forward() (reference chada_vit.py:272-289), so of the LAST block's output only
         # the CLS rows are ever read -- its attention output, out-projection, LayerNorms and FFN run on one row per image (K / V
@@ -124,6 +124,11 @@ class ChAdaViT(nn.Module):
         # row-wise work and 4/5 of that block's attention less.  (_last_block_cls_fwd / _bwd)
         self.cls_only_last_block = not os.environ.get("CHADAVIT_FULL_LAST_BLOCK")
         self.fp8_ln_emits_operand = True  # fp8 path: LayerNorm kernels also emit the following GEMM's quantised operand (measured neutral)
+        # fp8 path: the FFN's two dX GEMMs (dH = dz W2 under the ReLU pattern, dx1 = dz + dH W1) on the MX-scaled MFMA as well: dz is
+        # quantised in one pass, dH leaves its GEMM both as bf16 (the weight gradient's operand) and quantised, W^T has its own MX copy.
+        # cfg5 224 -> 230 images/s same box; gradient bar of tests/test_model_gpu.py::test_fp8_weight_path_vs_golden unchanged (worst
+        # per-tensor norm 6.7e-2 -> 7.1e-2, lowest cosine 0.941 -> 0.937).  CHADAVIT_FP8_DX=0: bf16 dX GEMMs (same-box A/B).
+        self.fp8_dx = os.environ.get("CHADAVIT_FP8_DX", "1") == "1"
         self._capture_blocks = None  # tests: {block index: None} -> filled with that block's output (packed rows) by the forward
 
     @staticmethod
@@ -505,6 +510,14 @@ def _block_bwd(m: ChAdaViT, flat: FlatParams, i: int, dx2, saved, rb: RaggedBatc
         dhid = torch.empty_like(hid)
         dx1 = ops.ffn_bwd_dx(dz, flat.ffn_packed_bwd(b + "linear1.weight"), rbits, dpre=dhid)
         dw(dz, hid, b + "linear2.weight", b + "linear2.bias")
+    elif m.weight_dtype == "fp8" and m.fp8_dx:
+        w2q, w2s = flat.mx8_t(b + "linear2.weight")
+        w1q, w1s = flat.mx8_t(b + "linear1.weight")
+        dzq, dzs = ops.mx8_quantize(dz)
+        dhid, (dhq, dhs) = ops.gemm_nt_mx8(dzq, dzs, w2q, w2s, epilogue=ops.EPI_RELUMASK, aux=hid, emit_q=True)
+        dw(dz, hid, b + "linear2.weight", b + "linear2.bias")
+        dx1 = ops.gemm_nt_mx8(dhq, dhs, w1q, w1s, epilogue=ops.EPI_RESID, aux=dz)
+        del dzq, dzs, dhq, dhs
     else:
         dhid = ops.gemm_nt(dz, flat.wt(b + "linear2.weight"), epilogue=ops.EPI_RELUMASK, aux=hid)
         dw(dz, hid, b + "linear2.weight", b + "linear2.bias")

@@ -38,7 +38,7 @@ constexpr int MX_NSTG = 3;
 #define MX_ST_AUX 2    // cache policy of the result stores (buffer aux bits: 2 = nt, 16 = sc1 write-through, 0 = plain)
 #endif
 
-enum { MXE_NONE = 0, MXE_RELU = 1, MXE_RESID = 3 };    // numbering as the bf16 GEMM's epilogues
+enum { MXE_NONE = 0, MXE_RELU = 1, MXE_RESID = 3, MXE_RELUMASK = 4 };    // numbering as the bf16 GEMM's epilogues
 
 struct Mx8Args {
   const uint8_t* Xq; const uint8_t* xs;   // [M, K] fp8, [K/32, lds_x] e8m0 (row stride lds_x >= M, multiple of 4)
@@ -210,11 +210,12 @@ __global__ __launch_bounds__((MX_NCONS + MX_NPROD) * 64, 3) void gemm_mx8_kernel
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  bf16x8 ep_rr[EPI == MXE_RESID ? 4 : 1][2];   // residual rows of the tile about to finish (see the prefetch below)
+  constexpr bool AUXR = EPI == MXE_RESID || EPI == MXE_RELUMASK;   // the epilogue reads an [M, N] bf16 operand (residual / ReLU pattern)
+  bf16x8 ep_rr[AUXR ? 4 : 1][2];   // its rows for the tile about to finish (see the prefetch below)
   int st_rd = 0, ckt = 0, ctile = 0;
   for (int q = 0; q < Q; ++q) {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // B_q
-    if constexpr (EPI == MXE_RESID) {
+    if constexpr (AUXR) {
       if (ckt == KT - 1) {
         // last k-step of output tile `ctile`: its residual rows are requested now and land behind this step's MFMAs.  The epilogue
         // then issues no load at all: a load's wait also waits for every OLDER store.
@@ -231,7 +232,7 @@ __global__ __launch_bounds__((MX_NCONS + MX_NPROD) * 64, 3) void gemm_mx8_kernel
       }
     }
     const uint8_t* const stg = smem_o + st_rd * MX_STAGE;
-    mx8_consume<EPI == MXE_RESID>(stg, a_addr, b_addr, sa_addr, sb_addr, acc);
+    mx8_consume<AUXR>(stg, a_addr, b_addr, sa_addr, sb_addr, acc);
     if (++ckt == KT) {
       // ---- epilogue of output tile `ctile`, per wave, no LDS and no barrier.  acc[nt][mt][i] = out[m = .. + mt*16 + r][n = .. +
       // nt*16 + 4 g + i]: written straight out that is 8-byte pieces scattered over 16 rows per instruction.  The four lanes
@@ -249,7 +250,7 @@ __global__ __launch_bounds__((MX_NCONS + MX_NPROD) * 64, 3) void gemm_mx8_kernel
       // ONE wait for the prefetched residual rows, here, before the first store (these empty statements "use" them): left to
       // itself hipcc waits for row k at slab k with a count that ignores the conditional stores in between, and every such wait
       // drains the stores of the slabs before it
-      if constexpr (EPI == MXE_RESID) {
+      if constexpr (AUXR) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) asm volatile("" ::"v"(ep_rr[mt][0]), "v"(ep_rr[mt][1]));
       }
@@ -317,6 +318,11 @@ __global__ __launch_bounds__((MX_NCONS + MX_NPROD) * 64, 3) void gemm_mx8_kernel
             for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(__builtin_bit_cast(float, qq[e]) + (float)rr[e]);
           } else {
             o = __builtin_bit_cast(bf16x8, u32x4{qq[0], qq[1], qq[2], qq[3]});
+            if constexpr (EPI == MXE_RELUMASK) {   // threshold_backward: the gradient passes where the forward's ReLU output was > 0
+              const bf16x8 rr = ep_rr[mt][k];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) o[e] = (float)rr[e] > 0.f ? o[e] : (bf16_t)0.f;
+            }
           }
           if (a.Out) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), out_rs, out_voff, (mt * 16 + 8 * k) * a.ldo * 2, MX_ST_AUX);
           if (a.OutQ) {  // (uniform) quantise the bf16 values: a 32-column MX block is the four lanes g = 0..3 of one (r & 7, r3)
@@ -434,7 +440,7 @@ extern "C" int chadavit_gemm_nt_mx8_q(const void* Xq, const void* xs, int lds_x,
   if (Out == nullptr) ldo = 8;
   if (N % MX_BN != 0 || K % MX_BK != 0 || ldo % 8 != 0 || (long long)M * K >= (1ll << 32) || (long long)N * K >= (1ll << 32)) return 2;
   if (lds_x < M || lds_w < N || lds_x % 4 != 0 || lds_w % 4 != 0 || (((uintptr_t)xs | (uintptr_t)ws) & 3) != 0) return 2;
-  if (epilogue == MXE_RESID && (!aux || ldaux % 8 != 0)) return 1;
+  if ((epilogue == MXE_RESID || epilogue == MXE_RELUMASK) && (!aux || ldaux % 8 != 0)) return 1;
   Mx8Args a;
   a.Xq = reinterpret_cast<const uint8_t*>(Xq); a.xs = reinterpret_cast<const uint8_t*>(xs);
   a.Wq = reinterpret_cast<const uint8_t*>(Wq); a.ws = reinterpret_cast<const uint8_t*>(ws);
@@ -448,6 +454,7 @@ extern "C" int chadavit_gemm_nt_mx8_q(const void* Xq, const void* xs, int lds_x,
     case MXE_NONE: hipLaunchKernelGGL((gemm_mx8_kernel<MXE_NONE>), grid, dim3((MX_NCONS + MX_NPROD) * 64), 0, s, a); break;
     case MXE_RELU: hipLaunchKernelGGL((gemm_mx8_kernel<MXE_RELU>), grid, dim3((MX_NCONS + MX_NPROD) * 64), 0, s, a); break;
     case MXE_RESID: hipLaunchKernelGGL((gemm_mx8_kernel<MXE_RESID>), grid, dim3((MX_NCONS + MX_NPROD) * 64), 0, s, a); break;
+    case MXE_RELUMASK: hipLaunchKernelGGL((gemm_mx8_kernel<MXE_RELUMASK>), grid, dim3((MX_NCONS + MX_NPROD) * 64), 0, s, a); break;
     default: return 2;
   }
   CHADA_CHECK_LAUNCH();

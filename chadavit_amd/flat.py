@@ -119,6 +119,7 @@ class FlatParams:
             for i, w1 in enumerate(self._pk_src):
                 self._pkb[w1] = self._pkb_buf[pkb_desc[3 * i + 2]:pkb_desc[3 * i + 2] + nb]
         self._mx8: Dict[str, Tuple[int, torch.Tensor, torch.Tensor]] = {}
+        self._mx8_t: Dict[str, Tuple[int, torch.Tensor, torch.Tensor]] = {}
         self._cast_version = None
         self._cast_version_t = None
         self._manual_version = 0
@@ -164,6 +165,17 @@ class FlatParams:
             wq, ws = ops.mx8_quantize(self.w(name), q=hit[1] if hit else None, scales=hit[2] if hit else None)
             hit = (ver, wq, ws)
             self._mx8[name] = hit
+        return hit[1], hit[2]
+
+    def mx8_t(self, name: str) -> Tuple[torch.Tensor, torch.Tensor]:
+        """The OCP-MX fp8 copy of the TRANSPOSED weight (rows = in features, blocks of 32 along the out features): the W operand
+        of the dX GEMMs on the scaled MFMA (ChAdaViT.fp8_dx).  Quantised from the bf16 transpose once per parameter version."""
+        ver = self._cast_version_t
+        hit = self._mx8_t.get(name)
+        if hit is None or hit[0] != ver:
+            wq, ws = ops.mx8_quantize(self.wt(name), q=hit[1] if hit else None, scales=hit[2] if hit else None)
+            hit = (ver, wq, ws)
+            self._mx8_t[name] = hit
         return hit[1], hit[2]
 
     def f(self, name: str) -> torch.Tensor:
@@ -213,6 +225,8 @@ class FlatParams:
                 if self._pkb_desc is not None:
                     ops.ffn_pack_batched(self._t_buf, self._pkb_buf, self._pkb_desc, len(self._pkb), *self._pk_shape)
             self._cast_version_t = ver
+            for name in list(self._mx8_t):   # (eagerly, as the forward copies above)
+                self.mx8_t(name)
 
     # ---- gradient views handed to autograd users ---------------------------------------------------
     def grad_target(self, name: str, p: nn.Parameter) -> Tuple[torch.Tensor, bool]:

@@ -834,7 +834,7 @@ def mx8_quantize(x, relu=False, q=None, scales=None):
 
 @_timed(lambda xq, xs, wq, ws, *a, **k: ("gemm_nt_mx8", xq.shape[0], wq.shape[0], xq.shape[1], k.get("epilogue", 0)))
 def gemm_nt_mx8(xq, xs, wq, ws, bias=None, epilogue=EPI_NONE, aux=None, out=None, emit_q=False, want_out=True):
-    """out[M,N] bf16 = epilogue(deq(xq, xs) @ deq(wq, ws)^T + bias) on the MX-scaled fp8 MFMA (epilogues NONE / RELU / RESID).
+    """out[M,N] bf16 = epilogue(deq(xq, xs) @ deq(wq, ws)^T + bias) on the MX-scaled fp8 MFMA (epilogues NONE / RELU / RESID / RELUMASK).
     emit_q: also return (q, scales) = mx8_quantize(out) produced by the epilogue itself (the next GEMM's operand); with want_out=False
     the bf16 result is not written at all and None is returned in its place."""
     _req(xq, U8, "xq"); _req(wq, U8, "wq")

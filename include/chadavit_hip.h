@@ -345,7 +345,8 @@ int chadavit_bn_bwd(const chada_bf16* dy, const void* z, int z_f32, const float*
  * chadavit_mx8_quantize: x bf16 [R, K] (row stride ldx) -> q [R, K] e4m3 bytes (16-byte aligned), scales [K/32, lds] E8M0 bytes
  *   (row stride lds >= R, a multiple of 4; 4-byte aligned); relu != 0 applies max(x, 0) first.  K % 32 == 0. */
 int chadavit_mx8_quantize(const chada_bf16* x, int ldx, void* q, void* scales, int lds, int R, int K, int relu, void* stream);
-/* Out[M,N] (bf16) = epilogue(deq(Xq, xs) deq(Wq, ws)^T + bias); epilogue 0 = none, 1 = ReLU, 3 = + aux (bf16 [M, N], ld ldaux).
+/* Out[M,N] (bf16) = epilogue(deq(Xq, xs) deq(Wq, ws)^T + bias); epilogue 0 = none, 1 = ReLU, 3 = + aux (bf16 [M, N], ld ldaux),
+ * 4 = masked by aux > 0 (threshold_backward: the dX GEMM behind the ReLU).
  * xs [K/32, lds_x], ws [K/32, lds_w] as written by chadavit_mx8_quantize.  N % 128 == 0, K % 128 == 0. */
 int chadavit_gemm_nt_mx8(const void* Xq, const void* xs, int lds_x, const void* Wq, const void* ws, int lds_w, chada_bf16* Out, int ldo,
                          int M, int N, int K, const float* bias, int epilogue, const chada_bf16* aux, int ldaux, void* stream);

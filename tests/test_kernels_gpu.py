@@ -848,6 +848,13 @@ def test_gemm_nt_mx8(M, N, K):
     _close(out, torch.relu(ref + bias), 1e-2, 1e-2, "relu")
     out = ops.gemm_nt_mx8(xq, xs, wq, ws, bias=bias, epilogue=ops.EPI_RESID, aux=aux)
     _close(out, ref + bias + aux.float(), 1e-2, 2e-2, "resid")
+    # threshold_backward (the dX GEMM behind the ReLU): bit-exact masking of the plain product; its quantised copy bit-identical to
+    # mx8_quantize of the masked bf16 result
+    plain = ops.gemm_nt_mx8(xq, xs, wq, ws)
+    out, (oq, osc) = ops.gemm_nt_mx8(xq, xs, wq, ws, epilogue=ops.EPI_RELUMASK, aux=aux, emit_q=True)
+    assert torch.equal(out, torch.where(aux > 0, plain, torch.zeros_like(plain))), "relumask"
+    rq, rs = ops.mx8_quantize(out)
+    assert torch.equal(oq, rq) and torch.equal(osc, rs)
     exact = x.float() @ w.float().t()
     rel = float((ref - exact).norm() / exact.norm())
     assert rel <= 6e-2, rel

@@ -115,7 +115,8 @@ def test_dino_loss_module_vs_golden(name):
     assert abs(lf.center.double().sum().item() - float(g["center_new_sum"])) <= 1e-4 * (1 + abs(float(g["center_new_sum"])))
 
 
-def test_fp8_weight_path_vs_golden():
+@pytest.mark.parametrize("fp8_dx", [False, True])
+def test_fp8_weight_path_vs_golden(fp8_dx):
     """BASELINE.json configs[4]: ChAda-ViT-Base with the encoder's nn.Linear forwards on the MX-scaled fp8 MFMA (weights and their
     input activations in OCP-MX e4m3, fp32 accumulate; attention, LayerNorm, residuals and the whole backward in bf16 / fp32).
     Tolerance of SURVEY 8(c) for this path: CLS cosine >= 0.99 vs the reference's fp32 output; DINO loss abs <= 5e-2."""
@@ -146,15 +147,19 @@ def test_fp8_weight_path_vs_golden():
     model.load_state_dict(build_sd(D, PR))
     model = model.to(dev)
     assert model.backbone.weight_dtype == model.momentum_backbone.weight_dtype == "fp8"
+    model.backbone.fp8_dx = fp8_dx   # True: the FFN's two dX GEMMs on the MX-scaled MFMA too (same gradient bar)
     crops, labels, ncl = one_channel_collate_fn(P.make_images([int(c) for c in g["nch"]], [int(s) for s in g["sizes"]], seed=7))
     tr = Trainer(max_epochs=10, steps_per_epoch=10)
     tr.current_epoch = int(g["epoch"])
     tr.attach(model)
     model.current_epoch = int(g["epoch"])
     model.on_train_epoch_start()
-    loss = model.training_step(([c.to(dev) for c in crops], labels.to(dev), ncl), 1)
-    loss.backward()
+    with ops.LaunchProfiler() as prof:
+        loss = model.training_step(([c.to(dev) for c in crops], labels.to(dev), ncl), 1)
+        loss.backward()
     model.on_after_backward()
+    bwd_fp8 = sum(v["launches"] for k, v in prof.summary().items() if k[0] == "gemm_nt_mx8" and k[4] in (ops.EPI_RELUMASK,))
+    assert bwd_fp8 == (11 if fp8_dx else 0), bwd_fp8    # (the last block's backward runs on the CLS rows, in bf16)
     assert abs(loss.item() - float(g["loss"])) <= 5e-2, (loss.item(), float(g["loss"]))
     named = dict(model.named_parameters())
     tot_h = sum(named[str(n)].grad.double().norm().item() ** 2 for n in g["grad_names"]) ** 0.5
@@ -164,7 +169,7 @@ def test_fp8_weight_path_vs_golden():
     #   global gradient norm rel <= 5e-2 (measured 2.7e-2); EVERY tensor's norm rel <= 0.10 (tensors carrying >= 1e-3 of the largest
     #   norm; measured worst 6.7e-2, blocks.7.norm2.weight); cosine >= 0.93 on every tensor the golden holds in full (measured lowest
     #   0.941: cls_token, a single D-vector; the matrices are >= 0.98)
-    _fp8_gradient_bar(named, g, "fp8 step_base_c10")
+    _fp8_gradient_bar(named, g, "fp8 step_base_c10" + (" + fp8 dX" if fp8_dx else ""))
 
 
 def _fp8_gradient_bar(named, g, tag, norm_rel_global=5e-2, norm_rel_tensor=0.10, cos_min=0.93):
@@ -483,7 +488,9 @@ def test_bench_scale_replicated_batch_vs_golden(name, R_, rows, weight_dtype):
         assert sum(v["launches"] for k, v in summ.items() if k[0] == "attn_cls_fwd" and k[1] == rows) == 2
         assert sum(v["launches"] for k, v in summ.items() if k[0] == "attn_cls_bwd" and k[1] == rows) == 1
     if fp8:
-        assert sum(v["launches"] for k, v in summ.items() if k[0] == "gemm_nt_mx8" and k[1] == rows) == (4 * 11 + 1) * 2   # last block: QKV only
+        # forward: four per block and pass, the last block QKV only; backward: the FFN's two dX GEMMs of the 11 full-width blocks
+        assert sum(v["launches"] for k, v in summ.items() if k[0] == "gemm_nt_mx8" and k[1] == rows) == \
+            (4 * 11 + 1) * 2 + (2 * 11 if model.backbone.fp8_dx else 0)
         assert abs(loss.item() - float(g["loss"])) <= 5e-2, (loss.item(), float(g["loss"]))
         _fp8_gradient_bar(dict(model.named_parameters()), g, f"fp8 {name} x {R_}")
         return
