@@ -10,7 +10,6 @@ use chadavit_amd.methods.dino.DINO directly as a LightningModule instead.
 """
 from __future__ import annotations
 
-from types import SimpleNamespace
 from typing import Iterable, Optional
 
 import torch
