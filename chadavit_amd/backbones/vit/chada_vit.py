@@ -212,8 +212,8 @@ class ChAdaViT(nn.Module):
             raise RuntimeError(f"an image has more than {max_channels} channels")  # torch.stack fails in the reference (:232)
         S = x.shape[-1]
         ps = self.token_learner.patch_size
-        if S % ps != 0:
-            raise RuntimeError("crop side must be a multiple of the patch size")
+        if S < ps:
+            raise RuntimeError("crop side smaller than the patch size")   # (a side that is no multiple of it loses its remainder, as in the conv)
         if rb is None:
             rb = ragged_batch(num_channels, (S // ps) ** 2, x.device)
         else:
@@ -282,7 +282,11 @@ def _tokenize(m: ChAdaViT, flat: FlatParams, x, rb: RaggedBatch, pos_patch, add_
     S = x.shape[-1]
     ps = m.token_learner.patch_size
     D = m.embed_dim
-    xs = x.reshape(-1, S, S).float().contiguous()
+    xs = x.reshape(-1, S, S)
+    if S % ps != 0:   # Conv2d(kernel = stride = patch) never reads the trailing S % patch rows / columns (chada_vit.py:118-134)
+        S = S // ps * ps
+        xs = xs[:, :S, :S]
+    xs = xs.float().contiguous()
     tokens = torch.empty((rb.T, D), device=x.device, dtype=torch.bfloat16)
     chan = flat.f("channel_token").view(m.max_channels, D) if add_chan else None
     if ps == 16:  # the conv unfold happens inside the GEMM's operand staging: no patch buffer in HBM

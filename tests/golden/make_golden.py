@@ -435,6 +435,11 @@ if __name__ == "__main__":
         golden_linear("linear_tiny_cls", 192, [3, 1, 2, 5, 1, 4], 224, False, False)
         golden_linear("linear_tiny_all_tokens_finetune", 192, [2, 2, 2, 2], 224, True, True, lr=2e-4)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "sizes":
+        # round 3: image sizes other than 224 / 96 -- 112 (7 x 7 patches), 100 (6 x 6, four pixels dropped by the stride-16 conv),
+        # 32 (2 x 2), 16 (ONE patch per channel) and 448 (28 x 28: 2 353 tokens for three channels); bicubic position embedding each
+        golden_backbone("backbone_tiny_sizes", 192, [2, 1, 3], [112, 100, 32, 16, 448], 61, 62)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "attnmap":
         golden_attnmap("attnmap_tiny", 192, 2, 224, 51, 52)
         golden_attnmap("attnmap_tiny96", 192, 3, 96, 53, 54)

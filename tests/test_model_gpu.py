@@ -46,7 +46,7 @@ def _backbone(D, seed_w, dev, return_all_tokens=False, num_heads=None):
     return m.to(dev)
 
 
-@pytest.mark.parametrize("name", ["backbone_tiny", "backbone_small", "backbone_base", "backbone_notebook12h"])
+@pytest.mark.parametrize("name", ["backbone_tiny", "backbone_small", "backbone_base", "backbone_notebook12h", "backbone_tiny_sizes"])
 def test_backbone_vs_golden(name):
     """backbone_notebook12h = the reference's DEFAULT constructor as HOW_TO_USE.ipynb cell 13 calls it: 12 heads (dh = 16) and a
     final LayerNorm eps of 1e-5 -- the feature-extraction path of the notebook, forward only."""
@@ -348,6 +348,50 @@ def test_training_step_vs_golden_and_oracle(name, fused_min_rows, dispatch):
         v = named[n].double().sum().item()
         assert abs(v - post[n]) <= 1e-4 * (abs(post[n]) + named[n].numel() ** 0.5), n
     assert all(p.grad is None for p in model.parameters())
+
+
+def test_training_step_at_other_image_sizes_vs_oracle():
+    """Crop sides other than 224 / 96: 112 and 100 as the two global crops (the latter loses four pixels per side to the stride-16 conv,
+    chada_vit.py:118-134) and 32 / 16 as local crops (four patches / ONE patch per channel: sequences of 2-13 tokens).  The oracle is
+    pinned to the reference at exactly these sizes by golden `backbone_tiny_sizes`; here the whole step -- loss, every gradient
+    (incl. the bicubic position-embedding resize's and the patch conv's), the centre -- is held against it."""
+    from chadavit_amd.data.channels_strategies import one_channel_collate_fn
+    from chadavit_amd.methods.dino import DINO
+    from chadavit_amd.trainer import Trainer
+    dev = _dev()
+    D, PR, nch, sizes = 192, 4096, [2, 1, 3, 1], [112, 100, 32, 16]
+    sd = build_sd(D, PR)
+    model = DINO(_cfg(D, PR, 2, 2))
+    model.load_state_dict(sd)
+    model = model.to(dev)
+    crops, labels, ncl = one_channel_collate_fn(P.make_images(nch, sizes, seed=17))
+    tr = Trainer(max_epochs=10, steps_per_epoch=10)
+    tr.current_epoch = 1
+    tr.attach(model)
+    model.current_epoch = 1
+    model.on_train_epoch_start()
+    loss = model.training_step(([c.to(dev) for c in crops], labels.to(dev), ncl), 1)
+    loss.backward()
+    model.on_after_backward()
+    tt = float(model.dino_loss_func.teacher_temp_schedule[1])
+    loss_o, grads_o, newc_o, aux = R.training_step(sd, crops, ncl, 2, tt, freeze_last_layer=False)
+    assert abs(loss.item() - float(loss_o)) <= 2e-2, (loss.item(), float(loss_o))
+    named = dict(model.named_parameters())
+    tot_h = tot_o = 0.0
+    worst = (1.0, None)
+    for n, go in grads_o.items():
+        if go is None:
+            assert named[n].grad is None, n
+            continue
+        gh = named[n].grad
+        assert gh is not None, n
+        tot_h += gh.double().norm().item() ** 2
+        tot_o += go.double().norm().item() ** 2
+        if float(go.norm()) > 1e-6 * np.sqrt(go.numel()):
+            worst = min(worst, (_cos(gh, go), n))
+    assert abs(np.sqrt(tot_h) - np.sqrt(tot_o)) <= 5e-2 * np.sqrt(tot_o), (np.sqrt(tot_h), np.sqrt(tot_o))
+    assert worst[0] >= 0.99, worst
+    np.testing.assert_allclose(model.dino_loss_func.center.float().cpu().numpy(), newc_o.numpy(), atol=2e-3)
 
 
 def test_training_step_with_batchnorm_in_the_head_vs_golden_and_oracle():

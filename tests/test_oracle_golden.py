@@ -29,7 +29,7 @@ def _backbone_case(g):
     return sd, crops, ncl, nch
 
 
-@pytest.mark.parametrize("name", ["backbone_tiny", "backbone_small", "backbone_base", "backbone_notebook12h"])
+@pytest.mark.parametrize("name", ["backbone_tiny", "backbone_small", "backbone_base", "backbone_notebook12h", "backbone_tiny_sizes"])
 def test_backbone_matches_reference(name):
     g = _load(name)
     sd, crops, ncl, nch = _backbone_case(g)
