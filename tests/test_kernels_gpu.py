@@ -928,7 +928,8 @@ def test_tokenizer_bwd_more_images_than_one_list_window():
     assert rel(dpos.view(p, D), ref_pos[1:]) < 1e-4
 
 
-@pytest.mark.parametrize("D,M,ch,n_seq", [(192, 603136, 3, 1024), (384, 278462, 10, 142), (768, 125504, 10, 64)])
+# (the fourth case: 2.3 x the bench's rows -- the hidden activation is 2.9 G elements / 5.8 GB, past 32-bit element AND byte offsets)
+@pytest.mark.parametrize("D,M,ch,n_seq", [(192, 603136, 3, 1024), (384, 278462, 10, 142), (768, 125504, 10, 64), (192, 1413600, 3, 2400)])
 def test_hot_kernels_at_bench_rows_equal_their_small_runs(D, M, ch, n_seq):
     """BASELINE-size launches (cfg2 at 512 images per GPU: 603 136 token rows, 1024 sequences of 589 tokens) through a
     size-independent property: every row / sequence is processed independently of its position, so a launch over R copies

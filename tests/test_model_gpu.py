@@ -480,7 +480,9 @@ def test_training_step_with_batchnorm_in_the_head_vs_golden_and_oracle():
 
 
 @pytest.mark.parametrize("name,R_,rows,weight_dtype", [("step_tiny_multicrop", 170, 600780, "bf16"), ("step_small_mixed", 70, 274820, "bf16"),
-                                                       ("step_base_c10", 25, 127500, "bf16"), ("step_base_c10", 25, 127500, "fp8")])
+                                                       ("step_base_c10", 25, 127500, "bf16"), ("step_base_c10", 25, 127500, "fp8"),
+                                                       # 2.35 x the bench's rows: activations past 32-bit element and byte offsets
+                                                       ("step_tiny_multicrop", 400, 1413600, "bf16")])
 def test_bench_scale_replicated_batch_vs_golden(name, R_, rows, weight_dtype):
     """The reference golden at BENCH SCALE through a size-independent property: a batch made of R copies of the golden's
     images has the same DINO loss (a mean over images; the centre starts at zero), the same centre update and the same
