@@ -133,20 +133,28 @@ class SpanAllReduce:
 
 
 class GradSync:
-    """Hooks a DINO module's backbone + head so their gradient spans are exchanged during backward."""
+    """Hooks a method module so its gradients are averaged over the ranks during / right after backward.
+    DINO: backbone + head spans from their `grad_ready_hook`s.  LinearModel (no head, no teacher): the backbone's spans when
+    fine-tuning, and the classifier's two small gradient tensors in `finish()`."""
 
     def __init__(self, group=None):
         self.reducer = SpanAllReduce(group)
         self.model = None
+        self._plain: List[torch.nn.Parameter] = []   # parameters outside the flat slabs whose gradients are exchanged in finish()
 
     def attach(self, model):
         self.model = model
         if self.reducer.world == 1:
             return self
-        if not getattr(model, "batch_crops", False):
-            raise RuntimeError("GradSync needs batch_crops=True (one backward per step, so every span is final when it fires)")
-        for mod in (model.backbone, model.head):
-            mod.grad_ready_hook = self._hook
+        if hasattr(model, "head"):
+            if not getattr(model, "batch_crops", False):
+                raise RuntimeError("GradSync needs batch_crops=True (one backward per step, so every span is final when it fires)")
+            for mod in (model.backbone, model.head):
+                mod.grad_ready_hook = self._hook
+        else:
+            if any(p.requires_grad for p in model.backbone.parameters()):
+                model.backbone.grad_ready_hook = self._hook
+            self._plain = [p for p in model.classifier.parameters() if p.requires_grad]
         self.broadcast_parameters()
         return self
 
@@ -157,16 +165,23 @@ class GradSync:
         self.reducer.reset_stats()
 
     def finish(self):
+        for p in self._plain:
+            if p.grad is not None:
+                g = p.grad.view(-1)
+                self.reducer.submit(g, 0, g.numel())
         self.reducer.finish()
 
     @torch.no_grad()
     def broadcast_parameters(self, src: int = 0):
         """Initial parameter / buffer sync (DDP broadcasts module state at construction)."""
         m = self.model
-        for mod in (m.backbone, m.momentum_backbone, m.head, m.momentum_head):
-            f = mod.flat_params()
-            dist.broadcast(f.flat, src=src)
-            f.mark_dirty()
-        dist.broadcast(m.dino_loss_func.center, src=src)
+        for name in ("backbone", "momentum_backbone", "head", "momentum_head"):
+            mod = getattr(m, name, None)
+            if mod is not None:
+                f = mod.flat_params()
+                dist.broadcast(f.flat, src=src)
+                f.mark_dirty()
+        if hasattr(m, "dino_loss_func"):
+            dist.broadcast(m.dino_loss_func.center, src=src)
         for p in m.classifier.parameters():
             dist.broadcast(p.data, src=src)

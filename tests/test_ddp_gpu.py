@@ -65,18 +65,19 @@ if world > 1:
 '''
 
 
-def _run(world):
+def _run(world, worker=None):
+    worker = WORKER if worker is None else worker
     env = dict(os.environ, CHADAVIT_ROOT=ROOT, PYTHONPATH=ROOT)
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     if world == 1:
-        cmd = [sys.executable, "-c", WORKER]
+        cmd = [sys.executable, "-c", worker]
     else:
         env.update(CHADAVIT_DIST_BACKEND="gloo", CHADAVIT_SINGLE_DEVICE="1")
         import tempfile
         tmpdir = tempfile.mkdtemp(prefix="chadavit_ddp_")  # scratch, never the repo tree
         path = os.path.join(tmpdir, "_ddp_worker.py")
         with open(path, "w") as f:
-            f.write(WORKER)
+            f.write(worker)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
                "--master-port", str(port), path]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
@@ -100,6 +101,76 @@ def test_two_ranks_match_single_process():
     assert two["center_pending_after_step"] and not one["center_pending_after_step"]
     for a, b in zip(one["g0"], two["g0"]):
         assert abs(a - b) <= 3e-2 * max(abs(a), abs(b)) + 5e-4
+
+
+LINEAR_WORKER = r'''
+import os, sys, json, torch
+sys.path.insert(0, os.environ["CHADAVIT_ROOT"])
+import torch.distributed as dist
+from chadavit_amd.parallel import GradSync, init_from_env
+from chadavit_amd.backbones import vit_channels
+from chadavit_amd.methods.linear import LinearModel
+from chadavit_amd.trainer import Trainer
+from chadavit_amd.data.channels_strategies import one_channel_collate_fn
+from oracle import procedural as P
+from tests.test_linear_gpu import _cfg
+rank, world, local = init_from_env()
+dev = torch.device("cuda", local)
+nch_all = [3, 1, 2, 4]
+per = len(nch_all) // world
+imgs_all = P.make_images(nch_all, [224], seed=13)
+x, labels, ncl = one_channel_collate_fn([imgs_all[i] for i in range(rank * per, (rank + 1) * per)])
+bb = vit_channels("dino", patch_size=16, embed_dim=192, return_all_tokens=False, max_number_channels=10)
+sdb = P.fill_state_dict(P.backbone_shapes(192), seed=1)
+cl = P.fill_state_dict({"weight": (7, 192), "bias": (7,)}, seed=21)
+if rank != 0:   # the broadcast at attach() must repair this
+    sdb = {k: v + 0.01 for k, v in sdb.items()}
+    cl = {k: v - 0.02 for k, v in cl.items()}
+bb.load_state_dict(sdb)
+m = LinearModel(bb, _cfg(192, False, 3, True, 7, True, 1e-3, 0.0, kwargs={"momentum": 0.9}))
+m.classifier.load_state_dict(cl)
+m = m.to(dev)
+tr = Trainer(max_epochs=4, steps_per_epoch=4, grad_sync=GradSync() if world > 1 else None).attach(m)
+m.train()
+named = dict(m.named_parameters())
+start = {"w": named["classifier.weight"].detach().double().sum().item(), "nw": named["backbone.norm.weight"].detach().double().sum().item()}
+loss = m.training_step((x.to(dev), labels.to(dev), ncl), 0)
+if tr.grad_sync is not None: tr.grad_sync.begin_backward()
+loss.backward()
+local_dw = named["classifier.weight"].grad.detach().clone()
+if tr.grad_sync is not None: tr.grad_sync.finish()
+torch.cuda.synchronize()
+g = lambda n: named[n].grad.detach()
+out = {"start": start, "dw": g("classifier.weight").flatten()[:16].cpu().tolist(), "dw_norm": g("classifier.weight").double().norm().item(),
+       "db": g("classifier.bias").cpu().tolist(), "nw": g("backbone.norm.weight")[:8].cpu().tolist(),
+       "gnorm": {n: g(n).double().norm().item() for n in ("backbone.blocks.0.linear1.weight", "backbone.blocks.11.self_attn.in_proj_weight",
+                                                           "backbone.pos_embed", "backbone.norm.weight", "backbone.token_learner.proj.weight")},
+       "moved_dw": (g("classifier.weight") - local_dw).double().norm().item() / local_dw.double().norm().item()}
+tr.optimizer.step()    # (fused SGD over the averaged gradients: must run on every rank without error)
+torch.cuda.synchronize()
+if rank == 0:
+    print("RESULT " + json.dumps(out), flush=True)
+if world > 1:
+    dist.barrier(); dist.destroy_process_group()
+'''
+
+
+@pytest.mark.timeout(1500)
+def test_linear_model_two_ranks_match_single_process():
+    """LinearModel fine-tuning under GradSync: world 2 (two images per rank, ranks starting from different weights) takes the same
+    optimiser step as world 1 on all four images -- the backbone's spans and the classifier's gradient tensors are averaged, the
+    parameters broadcast at attach()."""
+    one = _run(1, LINEAR_WORKER)
+    two = _run(2, LINEAR_WORKER)
+    assert two["start"] == one["start"]                      # rank 0's weights (rank 0 reports; the other rank started elsewhere)
+    assert one["moved_dw"] == 0.0
+    # the exchange changed rank 0's local classifier gradient (other images; the backbone's spans are exchanged INSIDE backward) ...
+    assert two["moved_dw"] > 0.05, two["moved_dw"]
+    for n, v in one["gnorm"].items():                                  # ... into the gradients of the four-image mean loss
+        assert abs(two["gnorm"][n] - v) <= 3e-2 * v + 1e-7, (n, v, two["gnorm"][n])
+    assert abs(one["dw_norm"] - two["dw_norm"]) <= 2e-2 * one["dw_norm"]
+    for a, b in zip(one["dw"] + one["db"] + one["nw"], two["dw"] + two["db"] + two["nw"]):
+        assert abs(a - b) <= 3e-2 * max(abs(a), abs(b)) + 5e-4, (a, b)
 
 
 def test_bench_contract_with_two_ranks():
