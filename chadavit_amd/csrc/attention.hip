@@ -1555,6 +1555,7 @@ extern "C" int chadavit_attn_fwd(const chada_bf16* qkv_, chada_bf16* out_, float
       hipLaunchKernelGGL((attn_fwd_dma_kernel<16, 2>), dim3(n_work * H), blk, 0, s, qkv, out, lse, cu_seqlens, work, T, D, H, scale);
       break;
     FWD_DMA_CASE(32, 2) FWD_DMA_CASE(64, 2) FWD_DMA_CASE(96, 2) FWD_DMA_CASE(192, 2)
+    FWD_CASE(128, 2) FWD_CASE(256, 1)   // embed_dim 256 / 512 with the factory's two heads: the register-staged kernels (cold path)
     case 384:  // eight waves x 16 query rows per 128-row tile (FwdDmaCfg<384>::NW)
       if (use_dma)
         hipLaunchKernelGGL((attn_fwd_dma_kernel<384, 1>), dim3(n_work * H), dim3(512), 0, s, qkv, out, lse, cu_seqlens, work, T, D, H, scale);
@@ -1584,7 +1585,7 @@ static int attn_bwd_launch(const chada_bf16* qkv_, const chada_bf16* out_, const
   const bf16_t* dout = reinterpret_cast<const bf16_t*>(dout_);
   bf16_t* dqkv = reinterpret_cast<bf16_t*>(dqkv_);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (dh != 32 && dh != 64 && dh != 96 && dh != 192 && dh != 384) return 2;
+  if (dh != 32 && dh != 64 && dh != 96 && dh != 128 && dh != 192 && dh != 256 && dh != 384) return 2;
   static const bool use_dma = getenv("CHADAVIT_ATTN_NO_DMA") == nullptr;
   const bool fuse_delta = (parts & 3) == 3;  // delta comes out of the dQ kernel; the stand-alone pass only if dQ is not run here
   if ((parts & 1) && !fuse_delta) {
@@ -1614,7 +1615,7 @@ static int attn_bwd_launch(const chada_bf16* qkv_, const chada_bf16* out_, const
       hipLaunchKernelGGL((attn_bwd_dkv_kernel<DHV, (DHV <= 96 ? 2 : 1)>), dim3((DHV <= 96 ? 1 : 2) * n_work * H), blk, 0, s, qkv, dout, lse, delta, dqkv, cu_seqlens, work, T, D, H, scale); \
     break;
   switch (dh) {
-    BWD_CASE(32, 2) BWD_CASE(64, 2) BWD_CASE(96, 2) BWD_CASE(192, 2) BWD_CASE(384, 1)
+    BWD_CASE(32, 2) BWD_CASE(64, 2) BWD_CASE(96, 2) BWD_CASE(192, 2) BWD_CASE(384, 1) BWD_CASE(128, 2) BWD_CASE(256, 1)
     default: return 2;
   }
 #undef BWD_CASE

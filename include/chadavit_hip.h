@@ -121,7 +121,8 @@ int chadavit_layernorm_bwd_pair(const chada_bf16* dy, const chada_bf16* x, const
  * key-padding mask (chada_vit.py:105-111): softmax(Q K^T / sqrt(dh)) V per image, per head.
  * qkv: bf16 [T, 3*D] rows = [q | k | v], head h uses columns [h*dh, (h+1)*dh) of each third
  * (in_proj_weight row order).  out: bf16 [T, D].  lse: fp32 [H, T] (natural log).
- * dh = D / H must be one of 16, 32, 64, 96, 128, 192, 384... (multiple of 32, <= 384) -- see .cpp.
+ * dh = D / H: 32, 64, 96, 128, 192, 256 or 384 (forward also 16; its backward is chadavit_attn_bwd_dh16).  96 / 192 / 384 are the
+ * benchmark's widths (LDS-DMA kernels); 128 / 256 (embed_dim 256 / 512 with two heads) run the register-staged kernels.
  * work: int32 [n_work, 2] = (image, tile index) built by the host from cu_seqlens; n_work must be a multiple of 8 and entry j
  * is executed on XCD j % 8: keep all tiles of an image at indices of one residue class (they then share that XCD's L2);
  * entries with image < 0 are padding.

@@ -307,7 +307,9 @@ def _attn_ref(qkv, cu, H):
                                        ([1, 2], 196, 768, 2), ([2, 3], 36, 192, 12), ([1, 2], 196, 192, 12),
                                        # the longest sequence the model can see (10 channels x 196 patches + CLS = 1961 tokens: cfg5's
                                        # "max-token stress"), at all three head widths
-                                       ([10, 1], 196, 192, 2), ([10], 196, 384, 2), ([1, 10], 196, 768, 2)])
+                                       ([10, 1], 196, 192, 2), ([10], 196, 384, 2), ([1, 10], 196, 768, 2),
+                                       # embed_dim 256 / 512 with the factory's two heads (dh 128 / 256: the register-staged kernels)
+                                       ([3, 2], 36, 256, 2), ([1, 3, 10], 196, 256, 2), ([2, 1], 36, 512, 2), ([1, 10], 196, 512, 2)])
 def test_attention_fwd_bwd(nch, p, D, H):
     from chadavit_amd import ops
     from chadavit_amd.ragged import RaggedBatch
@@ -1017,7 +1019,7 @@ def test_hot_kernels_at_bench_rows_equal_their_small_runs(D, M, ch, n_seq):
 
 @pytest.mark.parametrize("nch,p,D,H", [([3, 1, 10, 5], 196, 192, 2), ([1, 2], 36, 192, 2), ([2, 1, 1], 36, 384, 2), ([1], 4, 64, 2),
                                        ([3, 2], 36, 128, 2), ([2, 1], 36, 768, 2), ([1, 10], 196, 768, 2), ([2, 3], 36, 192, 12),
-                                       ([1] * 70, 1, 192, 2)])
+                                       ([1] * 70, 1, 192, 2), ([2, 1, 3], 36, 256, 2), ([1, 2], 196, 512, 2)])
 def test_attention_of_the_cls_rows(nch, p, D, H):
     """chadavit_attn_cls_fwd / _bwd against fp32 torch attention over all rows: the CLS rows of the output, and the gradient of a loss
     that reads only those rows (dQ exactly zero elsewhere, dK / dV of every row), and against the flash kernels' CLS rows."""

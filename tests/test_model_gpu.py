@@ -394,6 +394,48 @@ def test_training_step_at_other_image_sizes_vs_oracle():
     np.testing.assert_allclose(model.dino_loss_func.center.float().cpu().numpy(), newc_o.numpy(), atol=2e-3)
 
 
+@pytest.mark.parametrize("D", [128, 256, 512])
+def test_training_step_at_other_embed_dims_vs_oracle(D):
+    """`embed_dim` values between the benchmark's three (the factory keeps two heads: head widths 64 / 128 / 256): the GEMM + LayerNorm
+    chain and the register-staged attention kernels, whole step against the oracle."""
+    from chadavit_amd.data.channels_strategies import one_channel_collate_fn
+    from chadavit_amd.methods.dino import DINO
+    from chadavit_amd.trainer import Trainer
+    dev = _dev()
+    PR, nch, sizes = 4096, [2, 1, 3], [224, 224, 96]
+    sd = build_sd(D, PR)
+    model = DINO(_cfg(D, PR, 2, 1))
+    model.load_state_dict(sd)
+    model = model.to(dev)
+    crops, labels, ncl = one_channel_collate_fn(P.make_images(nch, sizes, seed=23))
+    tr = Trainer(max_epochs=10, steps_per_epoch=10)
+    tr.current_epoch = 1
+    tr.attach(model)
+    model.current_epoch = 1
+    model.on_train_epoch_start()
+    loss = model.training_step(([c.to(dev) for c in crops], labels.to(dev), ncl), 1)
+    loss.backward()
+    model.on_after_backward()
+    loss_o, grads_o, newc_o, aux = R.training_step(sd, crops, ncl, 2, float(model.dino_loss_func.teacher_temp_schedule[1]), freeze_last_layer=False)
+    assert abs(loss.item() - float(loss_o)) <= 2e-2, (loss.item(), float(loss_o))
+    named = dict(model.named_parameters())
+    tot_h = tot_o = 0.0
+    worst = (1.0, None)
+    for n, go in grads_o.items():
+        if go is None:
+            assert named[n].grad is None, n
+            continue
+        gh = named[n].grad
+        assert gh is not None, n
+        tot_h += gh.double().norm().item() ** 2
+        tot_o += go.double().norm().item() ** 2
+        if float(go.norm()) > 1e-6 * np.sqrt(go.numel()):
+            worst = min(worst, (_cos(gh, go), n))
+    assert abs(np.sqrt(tot_h) - np.sqrt(tot_o)) <= 5e-2 * np.sqrt(tot_o), (np.sqrt(tot_h), np.sqrt(tot_o))
+    assert worst[0] >= 0.99, worst
+    np.testing.assert_allclose(model.dino_loss_func.center.float().cpu().numpy(), newc_o.numpy(), atol=2e-3)
+
+
 def test_training_step_with_batchnorm_in_the_head_vs_golden_and_oracle():
     """`method_kwargs.use_bn_in_head = True` (reference src/methods/dino.py:59-77: BatchNorm1d behind the first two Linears of both
     heads): loss, gradients (incl. the BatchNorm scale / shift), the running estimates of both heads after one update per global
