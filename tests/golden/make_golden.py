@@ -401,6 +401,39 @@ def golden_linear(name, D, nch, S, return_all_tokens, finetune, n_cls=7, lr=0.1,
     print("wrote", name, "loss", loss.item(), "val", v["val_loss"].item())
 
 
+CTOR_CASES = [  # (constructor kwargs, channels per image, crop sides, seed)
+    (dict(embed_dim=192, patch_size=8, img_size=[64], depth=3, num_heads=2, max_number_channels=10), [2, 1], [64, 32], 71),
+    (dict(embed_dim=192, patch_size=16, img_size=[224], depth=2, num_heads=6, max_number_channels=5), [3, 5, 1], [224], 72),
+    (dict(embed_dim=128, patch_size=16, img_size=[96], depth=2, num_heads=2, max_number_channels=10), [1, 4], [96, 224], 73),
+]
+
+
+def golden_ctor(name):
+    """Constructor arguments other than the factory's (chada_vit.py:138-183): patch 8 on a 64-pixel grid, a 96-pixel position grid
+    (interpolated UP to 224), depth 2 / 3, six heads, and max_number_channels = 5 -- which makes the reference skip the channel
+    tokens altogether (forward() calls the tokenizer with its default max_channels = 10, chada_vit.py:219, 248, 274)."""
+    out = {"n_cases": len(CTOR_CASES)}
+    for ci, (kw, nch, sizes, seed) in enumerate(CTOR_CASES):
+        m = ref.ChAdaViT(return_all_tokens=False, **kw)
+        D = kw["embed_dim"]
+        m.load_state_dict(P.fill_state_dict(P.backbone_shapes(D, depth=kw["depth"], patch=kw["patch_size"], img=kw["img_size"][0],
+                                                              max_channels=kw["max_number_channels"]), seed=seed))
+        imgs = P.make_images(nch, sizes, seed=seed + 100)
+        crops, labels, ncl = ref.one_channel_collate_fn([(i, c, l) for i, (c, l) in enumerate(imgs)])
+        crops = crops if isinstance(crops, list) else [crops]
+        with torch.no_grad():
+            for k, x in enumerate(crops):
+                m.return_all_tokens = False
+                out[f"c{ci}_cls{k}"] = f32(m(x, k, ncl))
+                m.return_all_tokens = True
+                allt = m(x, k, ncl)
+                rs = row_subset(allt.shape[0])
+                out[f"c{ci}_all{k}_rows"], out[f"c{ci}_all{k}_vals"] = rs, f32(allt[rs])
+                out[f"c{ci}_all{k}_shape"], out[f"c{ci}_all{k}_sum"] = np.asarray(allt.shape), np.float64(allt.double().sum().item())
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "val":
         golden_val("val_tiny", 192, 4096, [2, 1, 4], [224, 224, 96], 2)
@@ -434,6 +467,9 @@ if __name__ == "__main__":
         # and on all patch tokens flattened per image (two channels each, fine-tuning the backbone)
         golden_linear("linear_tiny_cls", 192, [3, 1, 2, 5, 1, 4], 224, False, False)
         golden_linear("linear_tiny_all_tokens_finetune", 192, [2, 2, 2, 2], 224, True, True, lr=2e-4)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "ctor":
+        golden_ctor("backbone_ctor_args")
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "sizes":
         # round 3: image sizes other than 224 / 96 -- 112 (7 x 7 patches), 100 (6 x 6, four pixels dropped by the stride-16 conv),

@@ -206,6 +206,53 @@ def test_backbone_errors_and_surface():
         m(x.cpu(), 0, [[3]])  # no CPU fallback
 
 
+def test_backbone_with_other_constructor_arguments_vs_golden_and_oracle():
+    """ChAdaViT(...) with patch 8 on a 64-pixel grid, a 96-pixel position grid interpolated up to 224, depth 2 / 3, six heads, and
+    max_number_channels = 5 (the reference then adds no channel tokens, chada_vit.py:219, 248): CLS and all-token outputs against the
+    golden of the reference built with the same arguments, gradients of a scalar of the all-token output against the oracle."""
+    from chadavit_amd.backbones.vit.chada_vit import ChAdaViT
+    from tests.golden_util import CTOR_CASES, ctor_case_state
+    dev = _dev()
+    g = np.load(os.path.join(GOLDEN, "backbone_ctor_args.npz"))
+    for ci, (kw, nch, sizes, seed) in enumerate(CTOR_CASES):
+        sd = ctor_case_state(kw, seed)
+        m = ChAdaViT(return_all_tokens=False, **kw)
+        m.load_state_dict(sd)
+        m = m.to(dev)
+        crops, _, ncl = R.collate(P.make_images(nch, sizes, seed=seed + 100))
+        crops = crops if isinstance(crops, list) else [crops]
+        add_chan = kw["max_number_channels"] == 10
+        for k, x in enumerate(crops):
+            with torch.no_grad():
+                m.return_all_tokens = False
+                cls = m(x.to(dev), k, ncl)
+                m.return_all_tokens = True
+                allt = m(x.to(dev), k, ncl)
+            ref = torch.from_numpy(g[f"c{ci}_cls{k}"])
+            assert _cos(cls, ref) >= 0.999 and _rel(cls, ref) <= 2e-2, (ci, k, _cos(cls, ref), _rel(cls, ref))
+            assert list(allt.shape) == [int(v) for v in g[f"c{ci}_all{k}_shape"]]
+            rows = torch.from_numpy(g[f"c{ci}_all{k}_rows"])
+            assert _rel(allt[rows.to(dev)], torch.from_numpy(g[f"c{ci}_all{k}_vals"])) <= 2e-2, (ci, k)
+        # backward through the all-token output of the first crop
+        x = crops[0]
+        wgt = P.tensor(tuple(int(v) for v in g[f"c{ci}_all0_shape"]), f"ctor.w{ci}", 1.0, seed=5)
+        m.zero_grad(set_to_none=True)
+        (m(x.to(dev), 0, ncl).float() * wgt.to(dev)).sum().backward()
+        po = {n: v.detach().clone().requires_grad_(True) for n, v in sd.items()}
+        (R.backbone_ragged(po, x, ncl[0], kw["num_heads"], final_eps=1e-5, return_all_tokens=True, patch=kw["patch_size"],
+                           add_channel_token=add_chan) * wgt).sum().backward()
+        named = dict(m.named_parameters())
+        worst = (1.0, None)
+        for n, v in po.items():
+            if v.grad is None or float(v.grad.norm()) <= 1e-6 * np.sqrt(v.numel()):
+                if n == "channel_token" and not add_chan:
+                    assert named[n].grad is None or float(named[n].grad.abs().max()) == 0.0   # never used: no gradient
+                continue
+            worst = min(worst, (_cos(named[n].grad, v.grad), n))
+            assert abs(float(named[n].grad.double().norm()) - float(v.grad.double().norm())) <= 6e-2 * float(v.grad.double().norm()) + 1e-6, (ci, n)
+        assert worst[0] >= 0.99, (ci, worst)
+
+
 def _cfg(D, PR, n_large, n_small, clip_grad=0.0, lr=5e-4, wd=1e-4, base_tau=0.9995, use_bn_in_head=False):
     from chadavit_amd.utils.misc import AttrDict
     return AttrDict({

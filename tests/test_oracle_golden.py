@@ -305,3 +305,24 @@ def test_linear_eval_step_matches_reference(name):
     a1, a5 = R.accuracy_at_k(lg2, labels2)
     assert a1 == pytest.approx(float(g["val_acc1"][0])) and a5 == pytest.approx(float(g["val_acc5"][0]))
     assert int(g["val_batch_size"]) == x2.shape[0]
+
+
+def test_backbone_with_other_constructor_arguments_matches_reference():
+    """patch 8 / a 64- or 96-pixel position grid / depth 2-3 / six heads / max_number_channels = 5 (channel tokens skipped by the
+    reference: chada_vit.py:219, 248): the oracle's generic code against the reference run with those constructor arguments."""
+    from tests.golden_util import CTOR_CASES, ctor_case_state
+    g = _load("backbone_ctor_args")
+    assert int(g["n_cases"]) == len(CTOR_CASES)
+    for ci, (kw, nch, sizes, seed) in enumerate(CTOR_CASES):
+        sd = ctor_case_state(kw, seed)
+        crops, _, ncl = R.collate(P.make_images(nch, sizes, seed=seed + 100))
+        crops = crops if isinstance(crops, list) else [crops]
+        add_chan = kw["max_number_channels"] == 10
+        for k, x in enumerate(crops):
+            with torch.no_grad():
+                cls = R.backbone_ragged(sd, x, ncl[k], kw["num_heads"], final_eps=1e-5, patch=kw["patch_size"], add_channel_token=add_chan)
+                allt = R.backbone_ragged(sd, x, ncl[k], kw["num_heads"], final_eps=1e-5, return_all_tokens=True, patch=kw["patch_size"],
+                                         add_channel_token=add_chan)
+            np.testing.assert_allclose(cls.numpy(), g[f"c{ci}_cls{k}"], atol=2e-5, rtol=1e-4, err_msg=f"case {ci} crop {k}")
+            assert list(allt.shape) == [int(v) for v in g[f"c{ci}_all{k}_shape"]]
+            np.testing.assert_allclose(allt[g[f"c{ci}_all{k}_rows"]].numpy(), g[f"c{ci}_all{k}_vals"], atol=2e-5, rtol=1e-4)
