@@ -75,10 +75,11 @@ __global__ __launch_bounds__(256) void weightnorm_fwd_kernel(const float* __rest
     if (l == 0) inv_norm[row] = inv;
   }
 }
-// dv = g*inv * (dw - vhat <dw, vhat>)   (g frozen: norm_last_layer, dino.py:83-84)
+// dv = g*inv * (dw - vhat <dw, vhat>);  dg = <dw, vhat> when the magnitudes are trained too (norm_last_layer = False; with the
+// default they are frozen at 1, dino.py:83-84, and dg is NULL)
 __global__ __launch_bounds__(256) void weightnorm_bwd_kernel(const float* __restrict__ dw, const float* __restrict__ v,
                                                              const float* __restrict__ g, const float* __restrict__ inv_norm,
-                                                             float* __restrict__ dv, int accumulate, int P, int K) {
+                                                             float* __restrict__ dv, float* __restrict__ dg, int accumulate, int P, int K) {
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   for (int row = blockIdx.x * 4 + w; row < P; row += gridDim.x * 4) {
     const float inv = inv_norm[row], gg = g[row];
@@ -87,6 +88,7 @@ __global__ __launch_bounds__(256) void weightnorm_bwd_kernel(const float* __rest
     float s = 0.f;
     for (int c = l; c < K; c += 64) s += dr[c] * vr[c] * inv;
     s = wave_sum(s);
+    if (dg && l == 0) dg[row] = (accumulate ? dg[row] : 0.f) + s;
     for (int c = l; c < K; c += 64) {
       const float o = gg * inv * (dr[c] - vr[c] * inv * s);
       float* dst = dv + (size_t)row * K + c;
@@ -556,7 +558,7 @@ __global__ __launch_bounds__(256) void knn_vote_kernel(const float* __restrict__
 
 }  // namespace
 
-extern "C" int chadavit_abi_version(void) { return 5; }
+extern "C" int chadavit_abi_version(void) { return 6; }
 
 extern "C" int chadavit_l2norm_fwd(const float* x, chada_bf16* y, float* inv_norm, int M, int N, void* stream) {
   CHADA_ENTRY();
@@ -584,14 +586,18 @@ extern "C" int chadavit_weightnorm_fwd(const float* v, const float* g, chada_bf1
   CHADA_CHECK_LAUNCH();
   return 0;
 }
-extern "C" int chadavit_weightnorm_bwd(const float* dw, const float* v, const float* g, const float* inv_norm, float* dv,
-                                       int accumulate, int P, int K, void* stream) {
+extern "C" int chadavit_weightnorm_bwd_g(const float* dw, const float* v, const float* g, const float* inv_norm, float* dv, float* dg,
+                                         int accumulate, int P, int K, void* stream) {
   CHADA_ENTRY();
   if (!dw || !v || !g || !inv_norm || !dv || P <= 0 || K <= 0) return 1;
   hipLaunchKernelGGL(weightnorm_bwd_kernel, dim3(grid_for((size_t)P * 64)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     dw, v, g, inv_norm, dv, accumulate, P, K);
+                     dw, v, g, inv_norm, dv, dg, accumulate, P, K);
   CHADA_CHECK_LAUNCH();
   return 0;
+}
+extern "C" int chadavit_weightnorm_bwd(const float* dw, const float* v, const float* g, const float* inv_norm, float* dv,
+                                       int accumulate, int P, int K, void* stream) {
+  return chadavit_weightnorm_bwd_g(dw, v, g, inv_norm, dv, nullptr, accumulate, P, K, stream);
 }
 
 extern "C" int chadavit_dino_loss(const float* student, const float* teacher, const float* center, float student_temp,

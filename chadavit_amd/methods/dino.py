@@ -220,9 +220,12 @@ class _HeadFn(torch.autograd.Function):
             P, K = flat.shapes[vname]
             dw = torch.empty((P, K), device=dev, dtype=torch.float32)
             ops.gemm_tn(dl, tn, dw, accumulate=False, workspace=ws)
-            ops.weightnorm_bwd(dw, flat.f(vname), flat.f("last_layer.weight_g").view(-1), winv, G(vname), accumulate=acc)
+            gname = "last_layer.weight_g"   # trainable only with method_kwargs.norm_last_layer = False (dino.py:83-84)
+            dg = G(gname).view(-1) if flat.params[flat.names.index(gname)].requires_grad else None
+            ops.weightnorm_bwd(dw, flat.f(vname), flat.f(gname).view(-1), winv, G(vname), accumulate=acc, dg=dg)
         elif not acc:
             G(vname).zero_()
+            G("last_layer.weight_g").zero_()
         dt = ops.l2norm_bwd(dtn, t, tinv)
         dh2 = ops.gemm_nt(dt, flat.wt(L2 + ".weight"), epilogue=ops.EPI_GELUBWD, aux=pre2)   # gradient w.r.t. the second GELU's input
         ops.gemm_tn(dt, h2, G(L2 + ".weight"), colsum=G(L2 + ".bias"), accumulate=acc, workspace=ws)
@@ -237,7 +240,7 @@ class _HeadFn(torch.autograd.Function):
         dx = ops.gemm_nt(dh1, flat.wt(L0 + ".weight"), out_fp32=True) if ctx.x_needs_grad else None
         ops.gemm_tn(dh1, xb, G(L0 + ".weight"), colsum=G(L0 + ".bias"), accumulate=acc, workspace=ws)
         for n, p in zip(flat.names, flat.params):
-            if p.requires_grad and not (n == vname and head.skip_last_layer_grad):
+            if p.requires_grad and not (n.startswith("last_layer.") and head.skip_last_layer_grad):   # (dino.py:374-376 drops both)
                 p.grad = G(n)
         pending = getattr(head, "_pending_backwards", 0)
         if pending > 1:   # (BatchNorm: one head call per crop -- the gradient slab is complete after the last of their backwards)

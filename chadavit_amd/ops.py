@@ -613,11 +613,14 @@ def weightnorm_fwd(v, g, w=None, w_t=None, inv=None):
     return w, w_t, inv
 
 
-def weightnorm_bwd(dw, v, g, inv, dv, accumulate=False):
+def weightnorm_bwd(dw, v, g, inv, dv, accumulate=False, dg=None):
+    """dv (+)= the gradient w.r.t. the directions v; dg (optional, [P]) (+)= the gradient w.r.t. the magnitudes g."""
     _req(dw, F32, "dw"); _req(v, F32, "v"); _req(dv, F32, "dv")
+    if dg is not None:
+        _req(dg, F32, "dg")
     P, K = v.shape
-    _chk(lib().chadavit_weightnorm_bwd(_ptr(dw), _ptr(v), _ptr(g), _ptr(inv), _ptr(dv), c_int(1 if accumulate else 0), c_int(P),
-                                       c_int(K), _stream()), "chadavit_weightnorm_bwd")
+    _chk(lib().chadavit_weightnorm_bwd_g(_ptr(dw), _ptr(v), _ptr(g), _ptr(inv), _ptr(dv), _ptr(dg), c_int(1 if accumulate else 0), c_int(P),
+                                         c_int(K), _stream()), "chadavit_weightnorm_bwd_g")
     return dv
 
 

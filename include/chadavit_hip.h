@@ -191,6 +191,10 @@ int chadavit_weightnorm_fwd(const float* v, const float* g, chada_bf16* w, chada
                             int K, void* stream);
 int chadavit_weightnorm_bwd(const float* dw, const float* v, const float* g, const float* inv_norm, float* dv,
                             int accumulate, int P, int K, void* stream);
+/* ... with the gradient of the magnitudes as well: dg[p] (+)= <dw[p], v[p]> / ||v[p]||  (method_kwargs.norm_last_layer = False leaves
+ * last_layer.weight_g trainable, dino.py:83-84); dg may be NULL. */
+int chadavit_weightnorm_bwd_g(const float* dw, const float* v, const float* g, const float* inv_norm, float* dv, float* dg,
+                              int accumulate, int P, int K, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * DINO loss forward+backward in one pass (losses/dino.py:69-101) and centre statistics (:103-118).

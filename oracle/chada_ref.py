@@ -331,7 +331,7 @@ def split_prefix(sd: Params, prefix: str) -> Params:
 
 def training_step(sd: Params, crops: List[torch.Tensor], num_channels: List[List[int]], num_large_crops: int,
                   teacher_temp: float, student_temp: float = 0.1, nheads: int = 2, padded: bool = False,
-                  freeze_last_layer: bool = True, clip_grad: float = 0.0):
+                  freeze_last_layer: bool = True, clip_grad: float = 0.0, norm_last_layer: bool = True):
     """Student fwd on global crops (-> z) and on local crops (backbone only, result unused: DINO does
     not override multicrop_forward, base.py:566-620); teacher fwd on global crops; loss over the 2x2
     cross pairs; backward.  Returns (loss, grads{name: tensor|None}, new_center, aux).
@@ -341,7 +341,8 @@ def training_step(sd: Params, crops: List[torch.Tensor], num_channels: List[List
     bb = {k: v.detach().clone().requires_grad_(True) for k, v in split_prefix(sd, "backbone.").items()}
     hd_all, thd_all = split_prefix(sd, "head."), split_prefix(sd, "momentum_head.")
     is_buf = lambda k: k.endswith(("running_mean", "running_var", "num_batches_tracked"))
-    hd = {k: v.detach().clone().requires_grad_(k != "last_layer.weight_g") for k, v in hd_all.items() if not is_buf(k)}
+    # (norm_last_layer, dino.py:83-84: the prototypes' magnitudes weight_g are frozen at their initial 1 -- or trained like the rest)
+    hd = {k: v.detach().clone().requires_grad_(k != "last_layer.weight_g" or not norm_last_layer) for k, v in hd_all.items() if not is_buf(k)}
     tbb = split_prefix(sd, "momentum_backbone.")
     thd = {k: v for k, v in thd_all.items() if not is_buf(k)}
     # BatchNorm running estimates of the two heads (use_bn_in_head): cloned, updated once per head call (= per global crop)

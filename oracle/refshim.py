@@ -246,7 +246,7 @@ def load_custom_transforms():
 def dino_cfg(embed_dim=192, num_prototypes=4096, num_large_crops=2, num_small_crops=0, max_epochs=10,
              proj_hidden_dim=2048, proj_output_dim=256, batch_size=4, lr=5e-4, weight_decay=1e-4,
              base_tau=0.9995, final_tau=1.0, warmup_teacher_temperature_epochs=3, clip_grad=0, freeze_last_layer=1,
-             ssl_val_loss=False, knn_eval=False, knn_k=20, knn_distance="euclidean", use_bn_in_head=False):
+             ssl_val_loss=False, knn_eval=False, knn_k=20, knn_distance="euclidean", use_bn_in_head=False, norm_last_layer=True):
     """Minimal cfg for the reference `DINO(cfg)` (SURVEY.md section 8(c) key list)."""
     return _AttrDict({
         "method": "dino",
@@ -263,6 +263,7 @@ def dino_cfg(embed_dim=192, num_prototypes=4096, num_large_crops=2, num_small_cr
         "momentum": {"base_tau": base_tau, "final_tau": final_tau},
         "method_kwargs": {"proj_hidden_dim": proj_hidden_dim, "proj_output_dim": proj_output_dim,
                           "num_prototypes": num_prototypes, "clip_grad": clip_grad, "use_bn_in_head": use_bn_in_head,
+                          "norm_last_layer": norm_last_layer,
                           "freeze_last_layer": freeze_last_layer,
                           "warmup_teacher_temperature_epochs": warmup_teacher_temperature_epochs},
         "ssl_val_loss": ssl_val_loss, "slurm": {"enabled": False}, "wandb": {"enabled": False},

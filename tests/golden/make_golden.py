@@ -100,10 +100,10 @@ def build_sd(D, PR, seeds=(1, 2, 3, 4, 5), hidden=2048, bott=256, use_bn=False):
 
 
 def golden_step(name, D, PR, nch, sizes, n_large, epoch, clip_grad=0.0, lr=5e-4, wd=1e-4, base_tau=0.9995,
-                max_steps=100, use_bn=False):
+                max_steps=100, use_bn=False, norm_last_layer=True):
     cfg = refshim.dino_cfg(embed_dim=D, num_prototypes=PR, num_large_crops=n_large,
                            num_small_crops=len(sizes) - n_large, clip_grad=clip_grad, lr=lr, weight_decay=wd,
-                           base_tau=base_tau, use_bn_in_head=use_bn)
+                           base_tau=base_tau, use_bn_in_head=use_bn, norm_last_layer=norm_last_layer)
     model = ref.DINO(cfg)
     sd = build_sd(D, PR, use_bn=use_bn)
     model.load_state_dict(sd)
@@ -134,7 +134,10 @@ def golden_step(name, D, PR, nch, sizes, n_large, epoch, clip_grad=0.0, lr=5e-4,
            "loss": np.float64(loss.item()), "grad_names": np.asarray(names), "grad_norms": np.asarray(gnorms),
            "none_grad_names": np.asarray(none_names),
            "center_new": f32(model.dino_loss_func.center)[0, :256],
-           "center_new_sum": np.float64(model.dino_loss_func.center.double().sum().item()), "use_bn": int(use_bn)}
+           "center_new_sum": np.float64(model.dino_loss_func.center.double().sum().item()), "use_bn": int(use_bn),
+           "norm_last_layer": int(norm_last_layer)}
+    if not norm_last_layer and dict(model.named_parameters())["head.last_layer.weight_g"].grad is not None:
+        out["grad::head.last_layer.weight_g"] = f32(dict(model.named_parameters())["head.last_layer.weight_g"].grad)
     if use_bn:  # the heads' BatchNorm running estimates after the step's forward passes (one update per global crop), and two BN gradients
         for n, b in model.named_buffers():
             if n.startswith(("head.", "momentum_head.")) and b.is_floating_point():
@@ -467,6 +470,12 @@ if __name__ == "__main__":
         # and on all patch tokens flattened per image (two channels each, fine-tuning the backbone)
         golden_linear("linear_tiny_cls", 192, [3, 1, 2, 5, 1, 4], 224, False, False)
         golden_linear("linear_tiny_all_tokens_finetune", 192, [2, 2, 2, 2], 224, True, True, lr=2e-4)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "steps_r03b":
+        # round 3: method_kwargs.norm_last_layer = False (the prototypes' magnitudes weight_g are trained, dino.py:83-84), at epoch 1
+        # (past freeze_last_layer) and at epoch 0 (both last-layer gradients dropped, dino.py:374-376)
+        golden_step("step_tiny_trained_prototype_norms", 192, 4096, [3, 1, 2], [224, 224, 96], 2, 1, norm_last_layer=False)
+        golden_step("step_tiny_trained_prototype_norms_epoch0", 192, 4096, [3, 1, 2], [224, 224, 96], 2, 0, norm_last_layer=False)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ctor":
         golden_ctor("backbone_ctor_args")

@@ -253,7 +253,7 @@ def test_backbone_with_other_constructor_arguments_vs_golden_and_oracle():
         assert worst[0] >= 0.99, (ci, worst)
 
 
-def _cfg(D, PR, n_large, n_small, clip_grad=0.0, lr=5e-4, wd=1e-4, base_tau=0.9995, use_bn_in_head=False):
+def _cfg(D, PR, n_large, n_small, clip_grad=0.0, lr=5e-4, wd=1e-4, base_tau=0.9995, use_bn_in_head=False, norm_last_layer=True):
     from chadavit_amd.utils.misc import AttrDict
     return AttrDict({
         "method": "dino",
@@ -266,7 +266,8 @@ def _cfg(D, PR, n_large, n_small, clip_grad=0.0, lr=5e-4, wd=1e-4, base_tau=0.99
         "scheduler": {"name": "none"},
         "momentum": {"base_tau": base_tau, "final_tau": 1.0},
         "method_kwargs": {"proj_hidden_dim": 2048, "proj_output_dim": 256, "num_prototypes": PR, "clip_grad": clip_grad,
-                          "freeze_last_layer": 1, "warmup_teacher_temperature_epochs": 3, "use_bn_in_head": use_bn_in_head},
+                          "freeze_last_layer": 1, "warmup_teacher_temperature_epochs": 3, "use_bn_in_head": use_bn_in_head,
+                          "norm_last_layer": norm_last_layer},
     })
 
 
@@ -481,6 +482,54 @@ def test_training_step_at_other_embed_dims_vs_oracle(D):
     assert abs(np.sqrt(tot_h) - np.sqrt(tot_o)) <= 5e-2 * np.sqrt(tot_o), (np.sqrt(tot_h), np.sqrt(tot_o))
     assert worst[0] >= 0.99, worst
     np.testing.assert_allclose(model.dino_loss_func.center.float().cpu().numpy(), newc_o.numpy(), atol=2e-3)
+
+
+@pytest.mark.parametrize("name", ["step_tiny_trained_prototype_norms", "step_tiny_trained_prototype_norms_epoch0"])
+def test_training_step_with_trained_prototype_norms_vs_golden_and_oracle(name):
+    """method_kwargs.norm_last_layer = False: the magnitudes `last_layer.weight_g` of the weight-normed prototypes are trained like
+    every other head parameter (dino.py:83-84) -- their gradient against the reference's (golden, element-wise) at epoch 1; at
+    epoch 0 (< freeze_last_layer) BOTH last-layer gradients are dropped (dino.py:374-376)."""
+    from chadavit_amd.data.channels_strategies import one_channel_collate_fn
+    from chadavit_amd.methods.dino import DINO
+    from chadavit_amd.trainer import Trainer
+    dev = _dev()
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    D, PR, epoch = int(g["D"]), int(g["P"]), int(g["epoch"])
+    nch, sizes = [int(c) for c in g["nch"]], [int(s) for s in g["sizes"]]
+    sd = build_sd(D, PR)
+    model = DINO(_cfg(D, PR, int(g["n_large"]), len(sizes) - int(g["n_large"]), norm_last_layer=False))
+    model.load_state_dict(sd)
+    model = model.to(dev)
+    assert model.head.last_layer.weight_g.requires_grad and not model.momentum_head.last_layer.weight_g.requires_grad
+    crops, labels, ncl = one_channel_collate_fn(P.make_images(nch, sizes, seed=7))
+    tr = Trainer(max_epochs=10, steps_per_epoch=10)
+    tr.current_epoch = epoch
+    tr.attach(model)
+    model.current_epoch = epoch
+    model.on_train_epoch_start()
+    loss = model.training_step(([c.to(dev) for c in crops], labels.to(dev), ncl), 1)
+    loss.backward()
+    model.on_after_backward()
+    assert abs(loss.item() - float(g["loss"])) <= 2e-2
+    named = dict(model.named_parameters())
+    for n in (str(n) for n in g["none_grad_names"]):
+        assert named[n].grad is None, n
+    tot_h = tot_r = 0.0
+    for n, gn in zip(g["grad_names"], g["grad_norms"]):
+        gh = named[str(n)].grad
+        assert gh is not None, str(n)
+        tot_h += gh.double().norm().item() ** 2
+        tot_r += float(gn) ** 2
+    assert abs(np.sqrt(tot_h) - np.sqrt(tot_r)) <= 5e-2 * np.sqrt(tot_r)
+    if epoch >= 1:
+        dg, ref = named["head.last_layer.weight_g"].grad, torch.from_numpy(g["grad::head.last_layer.weight_g"])
+        assert dg.shape == ref.shape and _cos(dg, ref) >= 0.99, _cos(dg, ref)
+        assert abs(float(dg.double().norm()) - float(ref.double().norm())) <= 5e-2 * float(ref.double().norm())
+    # the optimiser moves weight_g only when it has a gradient (AdamW's first step: lr * sign)
+    g0 = model.head.last_layer.weight_g.detach().clone()
+    tr.optimizer.step()
+    moved = (model.head.last_layer.weight_g.detach() - g0).abs().max().item()
+    assert (moved > 0) == (epoch >= 1), moved
 
 
 def test_training_step_with_batchnorm_in_the_head_vs_golden_and_oracle():
