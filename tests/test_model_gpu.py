@@ -532,6 +532,53 @@ def test_training_step_with_trained_prototype_norms_vs_golden_and_oracle(name):
     assert (moved > 0) == (epoch >= 1), moved
 
 
+def test_training_step_is_deterministic_under_allocator_churn():
+    """The same training step (golden step_tiny_fused_rows: whole-block kernels on the global passes, GEMM chain on the local one)
+    three times in one process, the caching allocator's free blocks refilled with large values and with NaN in between: loss and
+    every gradient tensor must come out bit-identical.  A kernel that reads a buffer before it is complete (a too generous
+    `s_waitcnt vmcnt(N)` in front of an LDS-DMA stage), outside its bounds or uninitialised shows up here as a run-to-run difference
+    -- the tolerance-based parity tests above let a few wrong rows of the TEACHER pass through (it has no gradient, and the
+    loss moved in its fourth digit)."""
+    from chadavit_amd.data.channels_strategies import one_channel_collate_fn
+    from chadavit_amd.methods.dino import DINO
+    from chadavit_amd.trainer import Trainer
+    dev = _dev()
+    g = np.load(os.path.join(GOLDEN, "step_tiny_fused_rows.npz"))
+    D, PR = int(g["D"]), int(g["P"])
+    nch, sizes = [int(c) for c in g["nch"]], [int(s) for s in g["sizes"]]
+    crops, labels, ncl = one_channel_collate_fn(P.make_images(nch, sizes, seed=7))
+
+    def poison(value):
+        bufs = [torch.full((mb * 1024 * 1024 // 2,), value, device=dev, dtype=torch.bfloat16) for mb in (1024, 512, 512, 256, 256, 128, 128, 64, 64, 32, 32, 16, 8, 4, 2, 1) for _ in range(3)]
+        torch.cuda.synchronize()
+        del bufs
+
+    ref = None
+    for val in (None, 3.0e4, float("nan")):
+        if val is not None:
+            poison(val)
+        model = DINO(_cfg(D, PR, int(g["n_large"]), len(sizes) - int(g["n_large"])))
+        model.load_state_dict(build_sd(D, PR))
+        model = model.to(dev)
+        tr = Trainer(max_epochs=10, steps_per_epoch=10)
+        tr.current_epoch = 1
+        tr.attach(model)
+        model.current_epoch = 1
+        model.on_train_epoch_start()
+        loss = model.training_step(([c.to(dev) for c in crops], labels.to(dev), ncl), 1)
+        loss.backward()
+        model.on_after_backward()
+        torch.cuda.synchronize()
+        got = (loss.detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+        if ref is None:
+            ref = got
+        else:
+            assert torch.equal(got[0], ref[0]), (float(got[0]), float(ref[0]), val)
+            bad = [n for n, t in got[1].items() if not torch.equal(t, ref[1][n])]
+            assert not bad, (val, len(bad), bad[:5])
+        del model, tr
+
+
 def test_training_step_with_batchnorm_in_the_head_vs_golden_and_oracle():
     """`method_kwargs.use_bn_in_head = True` (reference src/methods/dino.py:59-77: BatchNorm1d behind the first two Linears of both
     heads): loss, gradients (incl. the BatchNorm scale / shift), the running estimates of both heads after one update per global
