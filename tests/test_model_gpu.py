@@ -253,7 +253,8 @@ def test_backbone_with_other_constructor_arguments_vs_golden_and_oracle():
         assert worst[0] >= 0.99, (ci, worst)
 
 
-def _cfg(D, PR, n_large, n_small, clip_grad=0.0, lr=5e-4, wd=1e-4, base_tau=0.9995, use_bn_in_head=False, norm_last_layer=True):
+def _cfg(D, PR, n_large, n_small, clip_grad=0.0, lr=5e-4, wd=1e-4, base_tau=0.9995, use_bn_in_head=False, norm_last_layer=True,
+         hidden=2048, bott=256):
     from chadavit_amd.utils.misc import AttrDict
     return AttrDict({
         "method": "dino",
@@ -265,7 +266,7 @@ def _cfg(D, PR, n_large, n_small, clip_grad=0.0, lr=5e-4, wd=1e-4, base_tau=0.99
         "optimizer": {"name": "adamw", "batch_size": 4, "lr": lr, "weight_decay": wd, "classifier_lr": 0.1},
         "scheduler": {"name": "none"},
         "momentum": {"base_tau": base_tau, "final_tau": 1.0},
-        "method_kwargs": {"proj_hidden_dim": 2048, "proj_output_dim": 256, "num_prototypes": PR, "clip_grad": clip_grad,
+        "method_kwargs": {"proj_hidden_dim": hidden, "proj_output_dim": bott, "num_prototypes": PR, "clip_grad": clip_grad,
                           "freeze_last_layer": 1, "warmup_teacher_temperature_epochs": 3, "use_bn_in_head": use_bn_in_head,
                           "norm_last_layer": norm_last_layer},
     })
@@ -577,6 +578,50 @@ def test_training_step_is_deterministic_under_allocator_churn():
             bad = [n for n, t in got[1].items() if not torch.equal(t, ref[1][n])]
             assert not bad, (val, len(bad), bad[:5])
         del model, tr
+
+
+@pytest.mark.parametrize("nch,sizes,PR,hidden,bott", [([1], [224, 224], 4096, 2048, 256),            # ONE one-channel image
+                                                      ([2, 1], [224, 224, 96], 65536, 2048, 256),    # the linear yaml's 65 536 prototypes
+                                                      ([3, 1, 2], [224, 224], 1024, 512, 128)])      # another projector shape
+def test_training_step_other_head_shapes_and_tiny_batches_vs_oracle(nch, sizes, PR, hidden, bott):
+    """method_kwargs.{num_prototypes, proj_hidden_dim, proj_output_dim} other than the benchmark's, and a batch of one image: whole
+    step against the oracle (loss, every gradient, centre)."""
+    from chadavit_amd.data.channels_strategies import one_channel_collate_fn
+    from chadavit_amd.methods.dino import DINO
+    from chadavit_amd.trainer import Trainer
+    dev = _dev()
+    D = 192
+    sd = build_sd(D, PR, hidden=hidden, bott=bott)
+    model = DINO(_cfg(D, PR, 2, len(sizes) - 2, hidden=hidden, bott=bott))
+    model.load_state_dict(sd)
+    model = model.to(dev)
+    crops, labels, ncl = one_channel_collate_fn(P.make_images(nch, sizes, seed=29))
+    tr = Trainer(max_epochs=10, steps_per_epoch=10)
+    tr.current_epoch = 1
+    tr.attach(model)
+    model.current_epoch = 1
+    model.on_train_epoch_start()
+    loss = model.training_step(([c.to(dev) for c in crops], labels.to(dev), ncl), 1)
+    loss.backward()
+    model.on_after_backward()
+    loss_o, grads_o, newc_o, aux = R.training_step(sd, crops, ncl, 2, float(model.dino_loss_func.teacher_temp_schedule[1]), freeze_last_layer=False)
+    assert abs(loss.item() - float(loss_o)) <= 2e-2, (loss.item(), float(loss_o))
+    named = dict(model.named_parameters())
+    tot_h = tot_o = 0.0
+    worst = (1.0, None)
+    for n, go in grads_o.items():
+        if go is None:
+            assert named[n].grad is None, n
+            continue
+        gh = named[n].grad
+        assert gh is not None, n
+        tot_h += gh.double().norm().item() ** 2
+        tot_o += go.double().norm().item() ** 2
+        if float(go.norm()) > 1e-6 * np.sqrt(go.numel()):
+            worst = min(worst, (_cos(gh, go), n))
+    assert abs(np.sqrt(tot_h) - np.sqrt(tot_o)) <= 5e-2 * np.sqrt(tot_o), (np.sqrt(tot_h), np.sqrt(tot_o))
+    assert worst[0] >= 0.99, worst
+    np.testing.assert_allclose(model.dino_loss_func.center.float().cpu().numpy(), newc_o.numpy(), atol=2e-3)
 
 
 def test_training_step_with_batchnorm_in_the_head_vs_golden_and_oracle():
