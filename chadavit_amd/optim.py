@@ -75,7 +75,54 @@ class DeviceHyper:
         self.slots, self.active = list(slots), list(active)
 
 
-class FusedAdamW(torch.optim.Optimizer):
+class _SlabState:
+    """`state_dict()` / `load_state_dict()` in torch's own layout for optimisers that keep their moments in slabs beside the flat
+    parameter slabs: per parameter (indexed in param-group order, as torch packs them) `exp_avg` / `exp_avg_sq` / `step`
+    (torch.optim.Adam[W]) or `momentum_buffer` (torch.optim.SGD, the reference's LARS) -- what Lightning writes into its checkpoints
+    and what a checkpoint of the reference's optimiser holds, so a run can be resumed either way.  (With GraphedTrainStep the step
+    counters live on the device: `close()` it before saving.)"""
+
+    def _slab_views(self, f, n):   # -> [(torch state key, view of the slab shaped like the parameter)]
+        raise NotImplementedError
+
+    def _after_load(self, st):     # optimiser-specific flags implied by a loaded state
+        pass
+
+    def state_dict(self):
+        self._index()
+        added = []
+        for group in self.param_groups:
+            for p in group["params"]:
+                loc, st = self._where.get(id(p)), self.state.get(p)
+                if loc is None or not st:
+                    continue
+                for key, view in self._slab_views(*loc):
+                    st[key] = view.detach().clone()
+                    added.append((st, key))
+        try:
+            sd = super().state_dict()
+            sd["state"] = {k: dict(v) for k, v in sd["state"].items()}   # (torch hands out the live per-parameter dicts)
+            return sd
+        finally:
+            for st, key in added:
+                del st[key]
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._index()
+        for p, st in list(self.state.items()):
+            if isinstance(st.get("step"), torch.Tensor):
+                st["step"] = int(st["step"].item())
+            self._after_load(st)
+            loc = self._where.get(id(p))
+            if loc is None:
+                continue
+            for key, view in self._slab_views(*loc):
+                if key in st:
+                    view.copy_(st.pop(key))
+
+
+class FusedAdamW(_SlabState, torch.optim.Optimizer):
     decoupled = True   # AdamW; FusedAdam below: torch.optim.Adam's L2 form
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, modules: Iterable = ()):
@@ -88,6 +135,10 @@ class FusedAdamW(torch.optim.Optimizer):
         # leaves the per-parameter step counters to that object (chadavit_amd.graphed.GraphedTrainStep: the launches are captured
         # once and replayed with new values)
         self.device_hyper: Optional[DeviceHyper] = None
+
+    def _slab_views(self, f, n):
+        sl = self._slabs[id(f)]
+        return [("exp_avg", f.view(sl["m"], n)), ("exp_avg_sq", f.view(sl["v"], n))]
 
     def _index(self):
         """param id -> (FlatParams, name); rebuilt if a module re-created its slab."""
@@ -172,7 +223,7 @@ class FusedAdam(FusedAdamW):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, modules=modules)
 
 
-class FusedSGD(torch.optim.Optimizer):
+class FusedSGD(_SlabState, torch.optim.Optimizer):
     """torch.optim.SGD (the reference's "sgd", base.py:67-72) over the flat slabs: one launch per run of consecutive parameters that
     share a step count.  Momentum buffers live in a slab of the parameters' layout."""
 
@@ -183,6 +234,13 @@ class FusedSGD(torch.optim.Optimizer):
         self._modules = list(modules)
         self._bufs: Dict[int, torch.Tensor] = {}
         self._where: Dict[int, tuple] = {}
+
+    def _slab_views(self, f, n):
+        return [("momentum_buffer", f.view(self._bufs[id(f)], n))] if self.defaults["momentum"] != 0 else []
+
+    def _after_load(self, st):
+        if "momentum_buffer" in st:
+            st["seen"] = True
 
     def _index(self):
         flats = [m.flat_params() for m in self._modules]
@@ -238,7 +296,7 @@ class FusedSGD(torch.optim.Optimizer):
         return loss
 
 
-class FusedLARS(torch.optim.Optimizer):
+class FusedLARS(_SlabState, torch.optim.Optimizer):
     """LARS with the reference's semantics (src/utils/lars.py:112-167): layer-wise trust ratio eta*|p|/(|g| + wd*|p| + eps) and
     weight decay only where scaling applies; SGD momentum (PyTorch convention), optional Nesterov, clip_lr and
     exclude_bias_n_norm.  One HIP launch per (param group, flat slab): a block per tensor computes both norms and applies
@@ -257,6 +315,13 @@ class FusedLARS(torch.optim.Optimizer):
         self._bufs: Dict[int, torch.Tensor] = {}
         self._tables: Dict[tuple, tuple] = {}
         self._where: Dict[int, tuple] = {}
+
+    def _slab_views(self, f, n):
+        return [("momentum_buffer", f.view(self._bufs[id(f)], n))]
+
+    def _after_load(self, st):
+        if "momentum_buffer" in st:
+            st["init"] = True
 
     def _index(self):
         flats = [m.flat_params() for m in self._modules]

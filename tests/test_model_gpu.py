@@ -624,6 +624,67 @@ def test_training_step_other_head_shapes_and_tiny_batches_vs_oracle(nch, sizes, 
     np.testing.assert_allclose(model.dino_loss_func.center.float().cpu().numpy(), newc_o.numpy(), atol=2e-3)
 
 
+@pytest.mark.parametrize("opt_name,kwargs", [("adamw", {}), ("sgd", {"momentum": 0.9}), ("lars", {"momentum": 0.9, "eta": 0.02})])
+def test_optimizer_state_dict_resumes_bit_exact(opt_name, kwargs, tmp_path):
+    """`optimizer.state_dict()` of the fused optimisers holds the moments in torch's own per-parameter layout (what Lightning
+    checkpoints): two steps, save model + optimiser, load both into a fresh model, third step -- bit-identical to the uninterrupted
+    run; and torch.optim's own class accepts the saved state (the reference's optimiser could resume from it and vice versa)."""
+    from chadavit_amd.data.channels_strategies import one_channel_collate_fn
+    from chadavit_amd.methods.dino import DINO
+    from chadavit_amd.trainer import Trainer
+    from chadavit_amd.utils.checkpoint import load_checkpoint, save_checkpoint
+    dev = _dev()
+    D, PR = 192, 4096
+    crops, labels, ncl = one_channel_collate_fn(P.make_images([2, 1, 3], [224, 224, 96], seed=31))
+    batch = ([c.to(dev) for c in crops], labels.to(dev), ncl)
+
+    def make():
+        cfg = _cfg(D, PR, 2, 1, lr=1e-3 if opt_name == "adamw" else 0.05)
+        cfg.optimizer.name = opt_name
+        cfg.optimizer.kwargs = dict(kwargs)
+        m = DINO(cfg)
+        m.load_state_dict(build_sd(D, PR))
+        m = m.to(dev)
+        t = Trainer(max_epochs=10, steps_per_epoch=10)
+        t.current_epoch = 1
+        t.attach(m)
+        return m, t
+
+    a, ta = make()
+    for i in range(2):
+        ta.train_step(batch, 1 + i)
+    save_checkpoint(a, str(tmp_path / "m.ckpt"), epoch=1, global_step=ta.global_step)
+    osd = ta.optimizer.state_dict()
+    torch.save(osd, str(tmp_path / "o.pt"))
+    n_params = sum(len(g_["params"]) for g_ in osd["param_groups"])
+    key = "exp_avg" if opt_name == "adamw" else "momentum_buffer"
+    stepped = [i for i, st in osd["state"].items() if key in st]
+    assert len(stepped) >= 150 and len(stepped) <= n_params, (len(stepped), n_params)   # every parameter that got a gradient
+    flat_params = [p for g_ in ta.optimizer.param_groups for p in g_["params"]]
+    assert all(osd["state"][i][key].shape == flat_params[i].shape for i in stepped)
+    ta.train_step(batch, 3)
+    b, tb = make()
+    load_checkpoint(b, str(tmp_path / "m.ckpt"))
+    tb.optimizer.load_state_dict(torch.load(str(tmp_path / "o.pt"), weights_only=False))
+    tb.global_step = ta.global_step - 1
+    b.momentum_updater.cur_tau = None   # (recomputed below exactly as the uninterrupted run had it before its third step)
+    b.momentum_updater.cur_tau = float(a.momentum_updater.base_tau)
+    for i in range(2):   # tau schedule state of the uninterrupted run after two steps (host arithmetic, not part of any state_dict)
+        b.momentum_updater.update_tau(cur_step=i + 1, max_steps=tb.estimated_stepping_batches)
+    b.last_step = 2
+    tb.train_step(batch, 3)
+    sa, sb = a.state_dict(), b.state_dict()
+    bad = [k for k in sa if not torch.equal(sa[k], sb[k])]
+    assert not bad, bad[:6]
+    # torch's own optimiser class loads the saved state (same parameter order, same shapes)
+    ref_cls = {"adamw": torch.optim.AdamW, "sgd": torch.optim.SGD, "lars": torch.optim.SGD}[opt_name]
+    groups = [{"params": [torch.nn.Parameter(torch.zeros_like(p, device="cpu")) for p in g_["params"]]} for g_ in ta.optimizer.param_groups]
+    ref_opt = ref_cls(groups, lr=1e-3) if opt_name == "adamw" else ref_cls(groups, lr=0.05, momentum=0.9)
+    ref_opt.load_state_dict({"state": {i: {k: v for k, v in st.items() if k in ("step", "exp_avg", "exp_avg_sq", "momentum_buffer")}
+                                       for i, st in osd["state"].items()}, "param_groups": ref_opt.state_dict()["param_groups"]})
+    assert len(ref_opt.state) == len(stepped)
+
+
 def test_training_step_with_batchnorm_in_the_head_vs_golden_and_oracle():
     """`method_kwargs.use_bn_in_head = True` (reference src/methods/dino.py:59-77: BatchNorm1d behind the first two Linears of both
     heads): loss, gradients (incl. the BatchNorm scale / shift), the running estimates of both heads after one update per global
