@@ -685,6 +685,49 @@ def test_optimizer_state_dict_resumes_bit_exact(opt_name, kwargs, tmp_path):
     assert len(ref_opt.state) == len(stepped)
 
 
+def test_load_state_dict_after_training_steps_refreshes_every_shadow_copy():
+    """Loading weights into a model that has already trained (parameters are views of the flat slabs; bf16 shadows, transposes,
+    packed FFN streams, weight-normed prototypes are cached per parameter version): the next forward must see the loaded weights --
+    features and head outputs bit-identical to a fresh model holding them; also for weights written in place under no_grad."""
+    from chadavit_amd.data.channels_strategies import one_channel_collate_fn
+    from chadavit_amd.methods.dino import DINO
+    from chadavit_amd.trainer import Trainer
+    dev = _dev()
+    D, PR = 192, 4096
+    crops, labels, ncl = one_channel_collate_fn(P.make_images([2, 1, 3], [224, 224], seed=37))
+    batch = ([c.to(dev) for c in crops], labels.to(dev), ncl)
+    sd = build_sd(D, PR)
+    fresh = DINO(_cfg(D, PR, 2, 0))
+    fresh.load_state_dict(sd)
+    fresh = fresh.to(dev).eval()
+    fresh.list_num_channels = ncl
+    with torch.no_grad():
+        want = fresh(batch[0][0], 0)
+        want_t = fresh.momentum_forward(batch[0][0], 0)
+    m = DINO(_cfg(D, PR, 2, 0, lr=1e-2))
+    m.load_state_dict({k: v + 0.05 for k, v in sd.items()})
+    m = m.to(dev)
+    tr = Trainer(max_epochs=10, steps_per_epoch=10)
+    tr.current_epoch = 1
+    tr.attach(m)
+    for i in range(2):
+        tr.train_step(batch, 1 + i)
+    m.load_state_dict(sd)
+    m.eval()
+    m.list_num_channels = ncl
+    with torch.no_grad():
+        got = m(batch[0][0], 0)
+        got_t = m.momentum_forward(batch[0][0], 0)
+    for k in ("feats", "z", "logits"):
+        assert torch.equal(got[k], want[k]), k
+    assert torch.equal(got_t["feats"], want_t["feats"]) and torch.equal(got_t["z"], want_t["z"])
+    # in-place edits under no_grad are seen too
+    with torch.no_grad():
+        m.backbone.norm.weight.mul_(2.0)
+        fresh.backbone.norm.weight.mul_(2.0)
+        assert torch.equal(m(batch[0][0], 0)["feats"], fresh(batch[0][0], 0)["feats"])
+
+
 def test_training_step_with_batchnorm_in_the_head_vs_golden_and_oracle():
     """`method_kwargs.use_bn_in_head = True` (reference src/methods/dino.py:59-77: BatchNorm1d behind the first two Linears of both
     heads): loss, gradients (incl. the BatchNorm scale / shift), the running estimates of both heads after one update per global
