@@ -728,6 +728,60 @@ def test_load_state_dict_after_training_steps_refreshes_every_shadow_copy():
         assert torch.equal(m(batch[0][0], 0)["feats"], fresh(batch[0][0], 0)["feats"])
 
 
+@pytest.mark.parametrize("fused_min_rows", [None, 0])
+def test_gradient_accumulation_over_two_backward_passes(fused_min_rows):
+    """accumulate_grad_batches = 2 (Lightning: two training_step + backward rounds before one optimiser step, base.py:331-336): the
+    gradients after the second backward are the SUM of the two passes' own gradients -- every tensor, backbone and head, on both
+    dispatches of the block -- and zero_grad(set_to_none=True) starts the next accumulation from scratch."""
+    from chadavit_amd.data.channels_strategies import one_channel_collate_fn
+    from chadavit_amd.methods.dino import DINO
+    from chadavit_amd.trainer import Trainer
+    dev = _dev()
+    D, PR = 192, 4096
+    model = DINO(_cfg(D, PR, 2, 1))
+    model.load_state_dict(build_sd(D, PR))
+    model = model.to(dev)
+    if fused_min_rows is not None:
+        model.backbone.fused_min_rows = model.momentum_backbone.fused_min_rows = fused_min_rows
+    tr = Trainer(max_epochs=10, steps_per_epoch=10)
+    tr.current_epoch = 1
+    tr.attach(model)
+    model.current_epoch = 1
+    model.on_train_epoch_start()
+    batches = []
+    for seed, nch in ((41, [2, 1, 3]), (43, [1, 4])):
+        crops, labels, ncl = one_channel_collate_fn(P.make_images(nch, [224, 224, 96], seed=seed))
+        batches.append(([c.to(dev) for c in crops], labels.to(dev), ncl))
+    center0 = model.dino_loss_func.center.clone()
+
+    def grads_of(bs):
+        model.dino_loss_func.center.copy_(center0)     # (the centre moves with every loss call: same starting point for each variant)
+        tr.optimizer.zero_grad(set_to_none=True)
+        for b in bs:
+            model.training_step(b, 1).backward()
+        return {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    g0, g1 = grads_of(batches[:1]), grads_of(batches[1:])
+    model.dino_loss_func.center.copy_(center0)
+    tr.optimizer.zero_grad(set_to_none=True)
+    model.training_step(batches[0], 1).backward()
+    c1 = model.dino_loss_func.center.clone()
+    # second pass of the accumulation sees the centre the first one left: reproduce that for the separate reference of pass 2
+    tr.optimizer.zero_grad(set_to_none=True)
+    model.dino_loss_func.center.copy_(c1)
+    model.training_step(batches[1], 1).backward()
+    g1_after0 = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    both = grads_of(batches)
+    assert set(both) == set(g0) == set(g1_after0)
+    worst = (-1.0, "")
+    for n in both:
+        want = g0[n].double() + g1_after0[n].double()
+        err = float((both[n].double() - want).norm() / (want.norm() + 1e-30))
+        worst = max(worst, (err, n))
+    assert worst[0] <= 2e-3, worst     # (fp32 accumulation into the slab vs a sum of two fp32 results; bf16 never re-rounds a gradient)
+    assert any(float((g1[n] - g1_after0[n]).abs().max()) > 0 for n in g1)   # (the centre does matter: the test is not vacuous)
+
+
 def test_training_step_with_batchnorm_in_the_head_vs_golden_and_oracle():
     """`method_kwargs.use_bn_in_head = True` (reference src/methods/dino.py:59-77: BatchNorm1d behind the first two Linears of both
     heads): loss, gradients (incl. the BatchNorm scale / shift), the running estimates of both heads after one update per global
