@@ -782,6 +782,50 @@ def test_gradient_accumulation_over_two_backward_passes(fused_min_rows):
     assert any(float((g1[n] - g1_after0[n]).abs().max()) > 0 for n in g1)   # (the centre does matter: the test is not vacuous)
 
 
+def test_partially_frozen_backbone_and_head():
+    """requires_grad = False on some backbone / head parameters (a frozen patch embedding, a frozen first block, a frozen projector
+    bias): they get no gradient and the optimiser leaves them alone; every other gradient is what the unfrozen model computes."""
+    from chadavit_amd.data.channels_strategies import one_channel_collate_fn
+    from chadavit_amd.methods.dino import DINO
+    from chadavit_amd.trainer import Trainer
+    dev = _dev()
+    D, PR = 192, 4096
+    crops, labels, ncl = one_channel_collate_fn(P.make_images([2, 1, 3], [224, 224, 96], seed=47))
+    batch = ([c.to(dev) for c in crops], labels.to(dev), ncl)
+    frozen = ("backbone.token_learner.proj.weight", "backbone.pos_embed", "backbone.blocks.0.linear1.weight", "backbone.blocks.0.norm1.bias",
+              "backbone.blocks.5.self_attn.in_proj_weight", "head.mlp.2.bias")
+
+    def run(freeze):
+        m = DINO(_cfg(D, PR, 2, 1, lr=1e-3))
+        m.load_state_dict(build_sd(D, PR))
+        m = m.to(dev)
+        named = dict(m.named_parameters())
+        if freeze:
+            for n in frozen:
+                named[n].requires_grad_(False)
+        tr = Trainer(max_epochs=10, steps_per_epoch=10)
+        tr.current_epoch = 1
+        tr.attach(m)
+        m.current_epoch = 1
+        m.on_train_epoch_start()
+        before = {n: named[n].detach().clone() for n in frozen}
+        m.training_step(batch, 1).backward()
+        m.on_after_backward()
+        grads = {n: (None if p.grad is None else p.grad.detach().clone()) for n, p in m.named_parameters()}
+        tr.optimizer.step()
+        return grads, before, {n: named[n].detach().clone() for n in frozen}
+
+    g_all, _, _ = run(False)
+    g_frz, before, after = run(True)
+    for n in frozen:
+        assert g_frz[n] is None, n
+        assert torch.equal(before[n], after[n]), n
+    for n, gr in g_all.items():
+        if n in frozen or gr is None:
+            continue
+        assert g_frz[n] is not None and torch.equal(g_frz[n], gr), n
+
+
 def test_training_step_with_batchnorm_in_the_head_vs_golden_and_oracle():
     """`method_kwargs.use_bn_in_head = True` (reference src/methods/dino.py:59-77: BatchNorm1d behind the first two Linears of both
     heads): loss, gradients (incl. the BatchNorm scale / shift), the running estimates of both heads after one update per global
