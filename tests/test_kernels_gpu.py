@@ -1228,3 +1228,66 @@ def test_hot_kernels_are_deterministic(D, M, ch, n_seq):
             _, _, hn = cases["block no-grad"]()
             assert torch.equal(ref[3], ops.gemm_nt(hn, wq, bias=bq)), "fused QKV differs from the GEMM of hn"
         del ref
+
+
+def test_gemms_are_deterministic_at_every_shape_of_the_three_models():
+    """The GEMM entry points at every (M, N, K) the three model widths launch at bench size (forward, dX, the heads), every epilogue,
+    and the weight-gradient GEMM at every (T, I, J): four launches each, bit-identical (see test_hot_kernels_are_deterministic)."""
+    from chadavit_amd import ops
+    dev = _dev()
+    g = torch.Generator(device=dev); g.manual_seed(4321)
+    rnd = lambda *s, sc=1.0: (torch.randn(s, device=dev, generator=g) * sc)
+
+    def repeat_equal(name, fn, n=4):
+        ref = fn()
+        torch.cuda.synchronize()
+        ref = [t.clone() for t in (ref if isinstance(ref, (tuple, list)) else (ref,))]
+        for it in range(n - 1):
+            junk = torch.full((1 << 25,), float(it), device=dev)
+            got = fn()
+            got = got if isinstance(got, (tuple, list)) else (got,)
+            torch.cuda.synchronize()
+            for k, (u, v) in enumerate(zip(got, ref)):
+                assert torch.equal(u, v), f"{name}: output {k} of launch {it + 2} differs from the first"
+            del junk, got
+
+    nt_shapes = [(603136, 576, 192), (603136, 192, 576), (603136, 192, 192), (603136, 2048, 192), (603136, 192, 2048),
+                 (278462, 1152, 384), (278462, 384, 1152), (278462, 384, 384),
+                 (125504, 2304, 768), (125504, 768, 2304), (125504, 768, 768), (125504, 2048, 768), (125504, 768, 2048),
+                 (1024, 2048, 192), (1024, 2048, 2048), (1024, 256, 2048), (1024, 4096, 256), (1024, 65536, 256), (70001, 576, 192)]
+    for M, N, K in nt_shapes:
+        x, w, bias = rnd(M, K).bfloat16(), rnd(N, K, sc=1 / math.sqrt(K)).bfloat16(), rnd(N, sc=0.1)
+        aux = rnd(M, N).bfloat16()
+        repeat_equal(f"gemm_nt {M}x{N}x{K}", lambda: ops.gemm_nt(x, w, bias=bias))
+        if N <= 4096:
+            repeat_equal(f"gemm_nt {M}x{N}x{K} resid", lambda: ops.gemm_nt(x, w, bias=bias, epilogue=ops.EPI_RESID, aux=aux))
+            repeat_equal(f"gemm_nt {M}x{N}x{K} relumask", lambda: ops.gemm_nt(x, w, epilogue=ops.EPI_RELUMASK, aux=aux))
+        if M == 1024:
+            pre = torch.empty((M, N), device=dev, dtype=torch.bfloat16)
+            repeat_equal(f"gemm_nt {M}x{N}x{K} gelu", lambda: (ops.gemm_nt(x, w, bias=bias, epilogue=ops.EPI_GELU, aux_out=pre), pre))
+            repeat_equal(f"gemm_nt {M}x{N}x{K} gelubwd", lambda: ops.gemm_nt(x, w, epilogue=ops.EPI_GELUBWD, aux=aux))
+            repeat_equal(f"gemm_nt {M}x{N}x{K} fp32", lambda: ops.gemm_nt(x, w, bias=bias, out_fp32=True))
+        del x, w, aux
+    ws = torch.empty(32 * (2304 * 768 + 2304), device=dev)
+    for T, I, J in [(603136, 576, 192), (603136, 192, 192), (603136, 2048, 192), (603136, 192, 2048), (278462, 1152, 384), (278462, 2048, 384),
+                    (278462, 384, 2048), (125504, 2304, 768), (125504, 768, 768), (125504, 2048, 768), (125504, 768, 2048),
+                    (1024, 4096, 256), (1024, 2048, 2048), (1024, 256, 2048), (70001, 192, 2048)]:
+        a, b = rnd(T, I).bfloat16(), rnd(T, J).bfloat16()
+
+        def tn():
+            c, cs = torch.empty((I, J), device=dev), torch.empty(I, device=dev)
+            ops.gemm_tn(a, b, c, colsum=cs, workspace=ws)
+            return c, cs
+        repeat_equal(f"gemm_tn {T}x{I}x{J}", tn)
+        del a, b
+    for M, N, K in [(125504, 2304, 768), (125504, 2048, 768), (125504, 768, 2048), (125504, 768, 768), (1000, 768, 768)]:
+        x, w, bias = rnd(M, K).bfloat16(), rnd(N, K, sc=1 / math.sqrt(K)).bfloat16(), rnd(N, sc=0.1)
+        aux = rnd(M, N).bfloat16()
+        xq, xs = ops.mx8_quantize(x)
+        wq, wsq = ops.mx8_quantize(w)
+        flat = lambda r: (r[0],) + tuple(r[1])
+        repeat_equal(f"mx8 {M}x{N}x{K}", lambda: ops.gemm_nt_mx8(xq, xs, wq, wsq, bias=bias))
+        repeat_equal(f"mx8 {M}x{N}x{K} relu + q", lambda: flat(ops.gemm_nt_mx8(xq, xs, wq, wsq, bias=bias, epilogue=ops.EPI_RELU, emit_q=True)))
+        repeat_equal(f"mx8 {M}x{N}x{K} resid", lambda: ops.gemm_nt_mx8(xq, xs, wq, wsq, bias=bias, epilogue=ops.EPI_RESID, aux=aux))
+        repeat_equal(f"mx8 {M}x{N}x{K} relumask + q", lambda: flat(ops.gemm_nt_mx8(xq, xs, wq, wsq, epilogue=ops.EPI_RELUMASK, aux=aux, emit_q=True)))
+        del x, w, aux, xq, wq
