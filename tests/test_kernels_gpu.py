@@ -1225,8 +1225,12 @@ def test_hot_kernels_are_deterministic(D, M, ch, n_seq):
                 assert u is None or torch.equal(u, v), f"{name}: output {k} of run {it + 1} differs from the first run"
             del junk, got
         if name == "block no-grad + qkv":
-            _, _, hn = cases["block no-grad"]()
+            _, x2n, hn = cases["block no-grad"]()
             assert torch.equal(ref[3], ops.gemm_nt(hn, wq, bias=bq)), "fused QKV differs from the GEMM of hn"
+            tr_out = cases["block training"]()   # (x1, x2, hn, qkv, ...): the instance the step goldens hold against the reference
+            assert torch.equal(ref[1], x2n) and torch.equal(ref[1], tr_out[1]) and torch.equal(hn, tr_out[2]) and torch.equal(ref[3], tr_out[3]), \
+                "the no-grad instances' x2 / hn / qkv differ from the training instance's"
+            del tr_out
         del ref
 
 
