@@ -294,6 +294,7 @@ class DINO(_Base):
         self.exclude_bias_n_norm_wd = cfg.optimizer.exclude_bias_n_norm_wd
         self.scheduler = cfg.scheduler.name
         self.min_lr = cfg.scheduler.min_lr
+        self.lr_decay_steps = cfg.scheduler.lr_decay_steps
         self.warmup_start_lr = cfg.scheduler.warmup_start_lr
         self.warmup_epochs = cfg.scheduler.warmup_epochs
         self.scheduler_interval = cfg.scheduler.interval
@@ -368,6 +369,7 @@ class DINO(_Base):
         cfg.optimizer.classifier_lr = omegaconf_select(cfg, "optimizer.classifier_lr", None)
         cfg.accumulate_grad_batches = omegaconf_select(cfg, "accumulate_grad_batches", 1)
         cfg.scheduler.min_lr = omegaconf_select(cfg, "scheduler.min_lr", 0.0)
+        cfg.scheduler.lr_decay_steps = omegaconf_select(cfg, "scheduler.lr_decay_steps", None)
         cfg.scheduler.warmup_start_lr = omegaconf_select(cfg, "scheduler.warmup_start_lr", 3e-5)
         cfg.scheduler.warmup_epochs = omegaconf_select(cfg, "scheduler.warmup_epochs", 10)
         cfg.scheduler.interval = omegaconf_select(cfg, "scheduler.interval", "step")
@@ -434,8 +436,11 @@ class DINO(_Base):
             opt = FusedLARS(groups, lr=self.lr, weight_decay=self.weight_decay, modules=[self.backbone, self.head], **kw)
         if str(self.scheduler).lower() == "none":
             return opt
+        if self.scheduler == "step":   # base.py:472-473
+            from torch.optim.lr_scheduler import MultiStepLR
+            return [opt], [MultiStepLR(opt, self.lr_decay_steps)]
         if self.scheduler != "warmup_cosine":
-            raise RuntimeError(f"scheduler {self.scheduler} not supported (warmup_cosine | none)")
+            raise ValueError(f"{self.scheduler} not in (warmup_cosine, cosine, step)")   # (the reference's message, base.py:474-475)
         total = self.trainer.estimated_stepping_batches
         warm = self.warmup_epochs * (total / self.max_epochs) if self.scheduler_interval == "step" else self.warmup_epochs
         steps = total if self.scheduler_interval == "step" else self.max_epochs

@@ -271,3 +271,35 @@ def test_ragged_batch_cache_returns_the_same_description():
     assert len(_CACHE) == _CACHE_MAX
     b = ragged_batch([3, 1, 2], 196, dev)   # evicted meanwhile: rebuilt, same content
     assert b is not a and torch.equal(b.cu_seqlens, a.cu_seqlens) and torch.equal(b.work, a.work) and b.T == a.T
+
+
+def test_step_scheduler_and_unknown_scheduler_as_the_reference():
+    """scheduler.name = "step" -> MultiStepLR over scheduler.lr_decay_steps (base.py:472-473); an unknown name raises the reference's
+    ValueError (base.py:474-475).  Host logic only: configure_optimizers builds the fused optimiser without touching the GPU."""
+    import warnings
+    import pytest
+    from chadavit_amd.methods.dino import DINO
+    from chadavit_amd.trainer import Trainer
+    from chadavit_amd.utils.misc import AttrDict
+
+    def cfg(name):
+        return AttrDict({"method": "dino", "backbone": {"name": "vit_channels", "kwargs": {"embed_dim": 192, "patch_size": 16, "return_all_tokens": False,
+                                                                                       "max_number_channels": 10}},
+                         "data": {"dataset": "synthetic", "num_classes": 7, "max_img_channels": 10, "img_channels": 1, "num_large_crops": 2,
+                                  "num_small_crops": 0},
+                         "channels_strategy": "multi_channels", "mixed_channels": True, "weights_init": "random", "max_epochs": 10,
+                         "optimizer": {"name": "sgd", "batch_size": 4, "lr": 0.5, "weight_decay": 0.0, "classifier_lr": 0.1},
+                         "scheduler": {"name": name, "lr_decay_steps": [3, 6]}, "momentum": {"base_tau": 0.99, "final_tau": 1.0},
+                         "method_kwargs": {"proj_hidden_dim": 64, "proj_output_dim": 32, "num_prototypes": 128}})
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = DINO(cfg("step"))
+        tr = Trainer(max_epochs=10, steps_per_epoch=1).attach(m)
+        lrs = []
+        for _ in range(8):
+            lrs.append(tr.optimizer.param_groups[0]["lr"])
+            tr.scheduler.step()
+    assert lrs == pytest.approx([0.5, 0.5, 0.5, 0.05, 0.05, 0.05, 0.005, 0.005])
+    assert tr.optimizer.param_groups[1]["lr"] == pytest.approx(0.1 * 0.01)    # the classifier group decays with the rest
+    with pytest.raises(ValueError):
+        Trainer(max_epochs=10, steps_per_epoch=1).attach(DINO(cfg("cosine_restarts")))
