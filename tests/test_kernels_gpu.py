@@ -831,7 +831,8 @@ def test_mx8_quantize(R, K):
         assert bool((err <= amax[..., None] * 2.0 ** -4 + 1e-30).all())   # half an e4m3 ulp of the block's largest binade
 
 
-@pytest.mark.parametrize("M,N,K", [(1000, 2304, 768), (257, 768, 768), (300, 2048, 768), (130, 768, 2048), (64, 128, 128)])
+@pytest.mark.parametrize("M,N,K", [(1000, 2304, 768), (257, 768, 768), (300, 2048, 768), (130, 768, 2048), (64, 128, 128),
+                                   (125504, 2048, 768), (125504, 768, 2048)])   # (the last two: cfg5's FFN shapes at bench rows)
 def test_gemm_nt_mx8(M, N, K):
     """MX-scaled fp8 MFMA GEMM vs fp32 torch on the DEQUANTISED operands (so only the accumulation order differs), all epilogues;
     and vs the unquantised bf16 product within the quantisation noise (rel-L2 <= 6e-2: two e4m3 operands, 3 mantissa bits each)."""
