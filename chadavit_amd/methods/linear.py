@@ -163,11 +163,12 @@ class LinearModel(_Base):
         chadavit_amd.optim; schedulers warmup_cosine (per step or per epoch) | reduce | step | exponential | none."""
         from torch.optim.lr_scheduler import ExponentialLR, MultiStepLR, ReduceLROnPlateau
         from ..optim import FusedAdam, FusedAdamW, FusedLARS, FusedSGD, WarmupCosineLR, remove_bias_and_norm_from_weight_decay
+        lin_name = "classifier" if self.out_layer is getattr(self, "classifier", None) else "regressor"
         if not self.finetune:
-            groups: List[Dict[str, Any]] = [{"params": list(self.classifier.parameters())}]
+            groups: List[Dict[str, Any]] = [{"params": list(self.out_layer.parameters())}]
         else:
             groups = [{"name": "backbone", "params": list(self.backbone.parameters())},
-                      {"name": "classifier", "params": list(self.classifier.parameters())}]
+                      {"name": lin_name, "params": list(self.out_layer.parameters())}]
         if self.exclude_bias_n_norm_wd:
             groups = remove_bias_and_norm_from_weight_decay(groups)
         assert self.optimizer in self._OPTIMIZERS
@@ -201,7 +202,7 @@ class LinearModel(_Base):
         """bf16 copy of the classifier weight with zero rows up to a multiple of 64, and the padded fp32 bias.  Rebuilt at every
         call (num_classes x features_dim elements): the fused optimisers update parameters in place through raw pointers, which
         no version counter sees."""
-        w, b = self.classifier.weight, self.classifier.bias
+        w, b = self.out_layer.weight, self.out_layer.bias
         Np = _pad64(w.shape[0])
         wb = torch.zeros((Np, w.shape[1]), device=w.device, dtype=torch.bfloat16)
         wb[: w.shape[0]] = w.detach()
@@ -209,9 +210,14 @@ class LinearModel(_Base):
         bp[: w.shape[0]] = b.detach()
         return wb, bp
 
+    @property
+    def out_layer(self) -> nn.Linear:
+        """The trained linear layer (`classifier` here, `regressor` in the regression subclass)."""
+        return self.classifier
+
     def _workspace(self, Np: int, K: int) -> torch.Tensor:
         need = 2 * (Np * K + Np)
-        dev = self.classifier.weight.device
+        dev = self.out_layer.weight.device
         if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
             self._ws = torch.empty(need, device=dev, dtype=torch.float32)
         return self._ws
@@ -232,8 +238,9 @@ class LinearModel(_Base):
         if feats.shape[1] != self.features_dim:
             raise RuntimeError(f"LinearModel: features of width {feats.shape[1]} for a classifier of {self.features_dim} inputs "
                                "(data.img_channels / return_all_tokens / mixed_channels do not describe this batch)")
-        if torch.is_grad_enabled() and (feats.requires_grad or self.classifier.weight.requires_grad):
-            logits = _ClassifierFn.apply(feats, self.classifier.weight, self.classifier.bias, self)
+        lin = self.out_layer
+        if torch.is_grad_enabled() and (feats.requires_grad or lin.weight.requires_grad):
+            logits = _ClassifierFn.apply(feats, lin.weight, lin.bias, self)
         else:
             wb, bp = self._operands()
             logits = ops.gemm_nt(feats.to(torch.bfloat16).contiguous(), wb, bias=bp, out_fp32=True)[:, : self.num_classes].contiguous()

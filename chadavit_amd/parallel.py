@@ -154,7 +154,7 @@ class GradSync:
         else:
             if any(p.requires_grad for p in model.backbone.parameters()):
                 model.backbone.grad_ready_hook = self._hook
-            self._plain = [p for p in model.classifier.parameters() if p.requires_grad]
+            self._plain = [p for p in getattr(model, "out_layer", model.classifier).parameters() if p.requires_grad]
         self.broadcast_parameters()
         return self
 
@@ -183,5 +183,5 @@ class GradSync:
                 f.mark_dirty()
         if hasattr(m, "dino_loss_func"):
             dist.broadcast(m.dino_loss_func.center, src=src)
-        for p in m.classifier.parameters():
+        for p in (m.out_layer if hasattr(m, "out_layer") else m.classifier).parameters():
             dist.broadcast(p.data, src=src)

@@ -461,6 +461,24 @@ def linear_step(bb: Params, W: torch.Tensor, b: torch.Tensor, x: torch.Tensor, n
     return loss.detach(), logits.detach(), feats.detach(), acc1, acc5, grads
 
 
+def regression_step(bb: Params, W: torch.Tensor, b: torch.Tensor, x: torch.Tensor, num_channels: Sequence[int], targets: torch.Tensor,
+                    finetune: bool, nheads: int = 2):
+    """RegressionModel.shared_step + backward (src/methods/regression.py:332-436): CLS features -> one output node, nn.MSELoss against
+    the targets unsqueezed to (B, 1).  Returns (loss, outputs (B, 1), grads) with "regressor.weight", "regressor.bias" and, when
+    fine-tuning, "backbone.<name>"."""
+    bbp = {k: v.detach().clone().requires_grad_(finetune) for k, v in bb.items()}
+    Wp, bp = W.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+    with torch.set_grad_enabled(finetune):
+        feats = backbone_ragged(bbp, x, num_channels, nheads)
+    out = feats @ Wp.t() + bp
+    loss = F.mse_loss(out, targets.unsqueeze(1))      # :420-427
+    loss.backward()
+    grads = {"regressor.weight": Wp.grad, "regressor.bias": bp.grad}
+    if finetune:
+        grads.update({"backbone." + k: v.grad for k, v in bbp.items() if v.grad is not None})
+    return loss.detach(), out.detach(), grads
+
+
 def sgd_step(param: torch.Tensor, grad: torch.Tensor, buf: Optional[torch.Tensor], lr: float, momentum: float = 0.0,
              weight_decay: float = 0.0):
     """torch.optim.SGD single-tensor update (linear.py:51-56 "sgd"; dampening 0, no Nesterov)."""

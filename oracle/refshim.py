@@ -207,6 +207,28 @@ def load_linear():
     return ns
 
 
+def load_regression():
+    """The reference's regression evaluation module (src/methods/regression.py); the torchmetrics regression metric objects it
+    constructs (absent here) are stand-ins that return 0 -- the goldens hold logits, the MSE loss and gradients only."""
+    ns = load_linear()
+    import torch
+
+    class _ZeroMetric(nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+
+        def forward(self, *a, **k):
+            return torch.zeros(())
+    tm = sys.modules["torchmetrics"]
+    for n in ("R2Score", "MeanSquaredError", "MeanAbsoluteError", "PearsonCorrCoef"):
+        if not hasattr(tm, n):
+            setattr(tm, n, _ZeroMetric)
+    if "src.methods.regression" not in sys.modules:
+        _load("src.methods.regression", "src/methods/regression.py")
+    ns.RegressionModel = sys.modules["src.methods.regression"].RegressionModel
+    return ns
+
+
 def linear_cfg(embed_dim=192, return_all_tokens=False, img_channels=3, mixed_channels=False, num_classes=7, finetune=False,
                optimizer="sgd", lr=0.1, weight_decay=0.0, scheduler="none", max_epochs=10, batch_size=4):
     """Minimal cfg for the reference `LinearModel(backbone, cfg)` (linear.py:65-232 reads these keys)."""

@@ -437,6 +437,49 @@ def golden_ctor(name):
     print("wrote", name)
 
 
+def golden_regression(name, D, nch, S, finetune, lr=0.01, momentum=0.9, wd=0.0):
+    """Reference RegressionModel (src/methods/regression.py): shared_step + backward + torch SGD, then a validation step; float
+    targets (the class index of the procedural images mapped to 0.37 * label - 1)."""
+    nsl = refshim.load_regression()
+    cfg = refshim.linear_cfg(embed_dim=D, return_all_tokens=False, img_channels=nch[0], mixed_channels=True, num_classes=1, finetune=finetune,
+                             lr=lr, weight_decay=wd)
+    bb = ref.vit_channels("dino", patch_size=16, embed_dim=D, return_all_tokens=False, max_number_channels=10)
+    bb.load_state_dict(P.fill_state_dict(P.backbone_shapes(D), seed=1))
+    model = nsl.RegressionModel(bb, cfg)
+    model.regressor.load_state_dict(P.fill_state_dict({"weight": (1, D), "bias": (1,)}, seed=23))
+    out = {"D": D, "nch": np.asarray(nch), "S": S, "finetune": int(finetune), "lr": lr, "momentum": momentum, "wd": wd}
+
+    def batch_of(seed):
+        X, labels, ncl = ref.one_channel_collate_fn([(i, c, l) for i, (c, l) in enumerate(P.make_images(nch, [S], seed=seed))])
+        return X, labels.float() * 0.37 - 1.0, ncl
+    batch = batch_of(9)
+    model.train()
+    params = model.regressor.parameters() if not finetune else [{"name": "backbone", "params": model.backbone.parameters()},
+                                                                 {"name": "regressor", "params": model.regressor.parameters()}]
+    opt = torch.optim.SGD(params, lr=lr, weight_decay=wd, momentum=momentum)
+    met = model.shared_step(batch, 0, 0)
+    met["loss"].backward()
+    with torch.no_grad():
+        fw = model(batch[0], 0)
+    out.update({"loss": np.float64(met["loss"].item()), "batch_size": int(met["batch_size"]), "logits": f32(fw["logits"]), "targets": f32(batch[1]),
+                "dW": f32(model.regressor.weight.grad), "db": f32(model.regressor.bias.grad)})
+    if finetune:
+        names, gn = [], []
+        for n, p in model.backbone.named_parameters():
+            if p.grad is not None:
+                names.append(n)
+                gn.append(p.grad.double().norm().item())
+        out["bb_grad_names"], out["bb_grad_norms"] = np.asarray(names), np.asarray(gn)
+    opt.step()
+    out["post_W"], out["post_b"] = f32(model.regressor.weight), f32(model.regressor.bias)
+    model.eval()
+    with torch.no_grad():
+        v = model.validation_step(batch_of(10), 0)
+    out["val_loss"] = np.float64(v["val_loss"].item())
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, "loss", met["loss"].item(), "val", v["val_loss"].item())
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "val":
         golden_val("val_tiny", 192, 4096, [2, 1, 4], [224, 224, 96], 2)
@@ -476,6 +519,9 @@ if __name__ == "__main__":
         # (past freeze_last_layer) and at epoch 0 (both last-layer gradients dropped, dino.py:374-376)
         golden_step("step_tiny_trained_prototype_norms", 192, 4096, [3, 1, 2], [224, 224, 96], 2, 1, norm_last_layer=False)
         golden_step("step_tiny_trained_prototype_norms_epoch0", 192, 4096, [3, 1, 2], [224, 224, 96], 2, 0, norm_last_layer=False)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "regression":
+        golden_regression("regression_tiny_finetune", 192, [3, 1, 2, 5, 1, 4], 224, True, lr=1e-4)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ctor":
         golden_ctor("backbone_ctor_args")

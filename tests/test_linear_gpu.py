@@ -178,3 +178,63 @@ def test_linear_model_rejects_what_the_reference_cannot_run():
     bad.channels_strategy = "one_channel"
     with pytest.raises(RuntimeError):
         LinearModel(bb, bad)
+
+
+def test_regression_model_step_vs_golden_and_oracle():
+    """chadavit_amd.methods.regression.RegressionModel (one `regressor` node, MSE on float targets, fine-tuning the backbone) against
+    the golden of the reference's RegressionModel (src/methods/regression.py) and the oracle; then the fused SGD step and a
+    validation step with R^2 / MSE / MAE / Pearson r against their definitions."""
+    from chadavit_amd.backbones import vit_channels
+    from chadavit_amd.methods.regression import RegressionModel
+    from chadavit_amd.trainer import Trainer
+    dev = torch.device("cuda:0")
+    g = np.load(os.path.join(GOLDEN, "regression_tiny_finetune.npz"), allow_pickle=False)
+    D, S, nch = int(g["D"]), int(g["S"]), [int(c) for c in g["nch"]]
+    bb = vit_channels("dino", patch_size=16, embed_dim=D, return_all_tokens=False, max_number_channels=10)
+    bbsd = P.fill_state_dict(P.backbone_shapes(D), seed=1)
+    bb.load_state_dict(bbsd)
+    m = RegressionModel(bb, _cfg(D, False, nch[0], True, 1, True, float(g["lr"]), float(g["wd"]), kwargs={"momentum": float(g["momentum"])}))
+    rg = P.fill_state_dict({"weight": (1, D), "bias": (1,)}, seed=23)
+    m.regressor.load_state_dict(rg)
+    m = m.to(dev)
+    assert sorted(k for k in m.state_dict() if not k.startswith("backbone.")) == ["regressor.bias", "regressor.weight"]
+
+    def batch_of(seed):
+        x, labels, ncl = R.collate(P.make_images(nch, [S], seed=seed))
+        return x.to(dev), (labels.float() * 0.37 - 1.0).to(dev), ncl
+    batch = batch_of(9)
+    tr = Trainer(max_epochs=10, steps_per_epoch=4).attach(m)
+    m.train()
+    met = m.shared_step(batch, 0, 0)
+    assert met["batch_size"] == int(g["batch_size"])
+    met["loss"].backward()
+    assert abs(float(met["loss"].detach()) - float(g["loss"])) <= 2e-2
+    with torch.no_grad():
+        out = m(batch[0], 0)["logits"]
+    np.testing.assert_allclose(out.float().cpu().numpy(), g["logits"], atol=3e-2, rtol=2e-2)
+    assert _cos(m.regressor.weight.grad, torch.from_numpy(g["dW"])) >= 0.999
+    np.testing.assert_allclose(m.regressor.bias.grad.cpu().numpy(), g["db"], atol=3e-3, rtol=2e-2)
+    _, _, og = R.regression_step(bbsd, rg["weight"], rg["bias"], batch[0].cpu(), nch, batch[1].cpu(), True)
+    grads = {n: p.grad for n, p in m.backbone.named_parameters() if p.grad is not None}
+    assert sorted(grads) == sorted(str(n) for n in g["bb_grad_names"])
+    for n, gn in zip(g["bb_grad_names"], g["bb_grad_norms"]):
+        got = float(grads[str(n)].double().norm())
+        assert abs(got - float(gn)) <= 6e-2 * float(gn) + 1e-5, (str(n), got, float(gn))
+        if float(gn) > 1e-3:   # (0.98 for the single D-vectors -- cls_token: 192 numbers of bf16 noise against a small gradient; measured 0.986)
+            assert _cos(grads[str(n)], og["backbone." + str(n)]) >= (0.98 if grads[str(n)].numel() <= D else 0.99), str(n)
+    tr.optimizer.step()
+    np.testing.assert_allclose(m.regressor.weight.detach().cpu().numpy(), g["post_W"], atol=1e-4, rtol=1e-3)
+    np.testing.assert_allclose(m.regressor.bias.detach().cpu().numpy(), g["post_b"], atol=1e-4, rtol=1e-3)
+    tr.optimizer.zero_grad(set_to_none=True)
+    m.eval()
+    vb = batch_of(10)
+    v = m.validation_step(vb, 0)
+    assert abs(float(v["val_loss"]) - float(g["val_loss"])) <= 3e-2 * max(1.0, float(g["val_loss"]))
+    with torch.no_grad():
+        o = m(vb[0], 0)["logits"].float().view(-1).cpu()
+    t = vb[1].cpu()
+    assert abs(float(v["val_mse"]) - float(((o - t) ** 2).mean())) < 1e-5 and abs(float(v["val_mae"]) - float((o - t).abs().mean())) < 1e-5
+    assert abs(float(v["val_r2"]) - float(1 - ((o - t) ** 2).sum() / ((t - t.mean()) ** 2).sum())) < 1e-4
+    assert abs(float(v["val_pcc"]) - float(np.corrcoef(o.numpy(), t.numpy())[0, 1])) < 1e-4
+    m.on_validation_epoch_end()
+    assert abs(m.logged_metrics()["val_mse"] - float(v["val_mse"])) < 1e-6 and not m.validation_step_metrics

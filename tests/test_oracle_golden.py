@@ -328,3 +328,37 @@ def test_backbone_with_other_constructor_arguments_matches_reference():
             np.testing.assert_allclose(cls.numpy(), g[f"c{ci}_cls{k}"], atol=2e-5, rtol=1e-4, err_msg=f"case {ci} crop {k}")
             assert list(allt.shape) == [int(v) for v in g[f"c{ci}_all{k}_shape"]]
             np.testing.assert_allclose(allt[g[f"c{ci}_all{k}_rows"]].numpy(), g[f"c{ci}_all{k}_vals"], atol=2e-5, rtol=1e-4)
+
+
+def test_regression_step_matches_reference():
+    """The oracle's restatement of RegressionModel.shared_step + backward + one SGD step + validation, against the reference
+    (src/methods/regression.py through oracle/refshim.load_regression; tests/golden/make_golden.py regression)."""
+    g = _load("regression_tiny_finetune")
+    D, S, nch = int(g["D"]), int(g["S"]), [int(c) for c in g["nch"]]
+    bb = P.fill_state_dict(P.backbone_shapes(D), seed=1)
+    rg = P.fill_state_dict({"weight": (1, D), "bias": (1,)}, seed=23)
+
+    def batch_of(seed):
+        x, labels, ncl = R.collate(P.make_images(nch, [S], seed=seed))
+        return x, labels.float() * 0.37 - 1.0, ncl[0]
+    x, t, ncl = batch_of(9)
+    np.testing.assert_allclose(t.numpy(), g["targets"], atol=0)
+    loss, out, grads = R.regression_step(bb, rg["weight"], rg["bias"], x, ncl, t, bool(g["finetune"]))
+    assert int(g["batch_size"]) == x.shape[0]
+    np.testing.assert_allclose(out.numpy(), g["logits"], atol=2e-5, rtol=1e-5)
+    assert abs(float(loss) - float(g["loss"])) <= 1e-5
+    np.testing.assert_allclose(grads["regressor.weight"].numpy(), g["dW"], atol=5e-6, rtol=1e-4)   # (fp32 noise of the features, ~1e-6)
+    np.testing.assert_allclose(grads["regressor.bias"].numpy(), g["db"], atol=5e-6, rtol=1e-4)
+    for n, gn in zip(g["bb_grad_names"], g["bb_grad_norms"]):
+        got = float(grads["backbone." + str(n)].double().norm())
+        assert abs(got - float(gn)) <= 1e-3 * float(gn) + 1e-6, (n, got, float(gn))
+    lr, mom, wd = float(g["lr"]), float(g["momentum"]), float(g["wd"])
+    W1, _ = R.sgd_step(rg["weight"], grads["regressor.weight"], None, lr, mom, wd)
+    b1, _ = R.sgd_step(rg["bias"], grads["regressor.bias"], None, lr, mom, wd)
+    np.testing.assert_allclose(W1.numpy(), g["post_W"], atol=1e-6, rtol=1e-5)
+    np.testing.assert_allclose(b1.numpy(), g["post_b"], atol=1e-6, rtol=1e-5)
+    bb1 = {k: (R.sgd_step(v, grads["backbone." + k], None, lr, mom, wd)[0] if "backbone." + k in grads else v) for k, v in bb.items()}
+    x2, t2, ncl2 = batch_of(10)
+    with torch.no_grad():
+        o2 = R.backbone_ragged(bb1, x2, ncl2, 2) @ W1.t() + b1
+    assert abs(float(torch.nn.functional.mse_loss(o2, t2.unsqueeze(1))) - float(g["val_loss"])) <= 2e-4 * max(1.0, float(g["val_loss"]))
