@@ -826,6 +826,50 @@ def test_partially_frozen_backbone_and_head():
         assert g_frz[n] is not None and torch.equal(g_frz[n], gr), n
 
 
+@pytest.mark.parametrize("workload", ["cfg2", "cfg5"])
+def test_bench_scale_step_is_deterministic(workload):
+    """bench.py's own workload (cfg2: 512 images, 603 136 token rows per global pass; cfg5: Base, fp8 path, side streams on) built
+    three times from the same seeds with the allocator's free blocks refilled in between: the loss and every gradient tensor of the
+    first training step bit-identical -- every kernel of the step at the size the benchmark times it (scratch/r3/fuzz_bench_scale.py
+    as a test; the teacher pass's QKV race of DESIGN section 0 made this differ in every run)."""
+    import gc
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    dev = _dev()
+    argv, sys.argv = sys.argv, [sys.argv[0]]
+    try:
+        args = bench.parse()
+    finally:
+        sys.argv = argv
+    wl = dict(bench.WORKLOADS[workload])
+    ref = None
+    for val in (None, 3.0e4, float("nan")):
+        if val is not None:
+            bufs = [torch.full((mb * 1024 * 1024 // 2,), val, device=dev, dtype=torch.bfloat16) for mb in (4096, 2048, 1024, 512, 256, 128, 64, 32, 16, 8, 4, 2, 1) for _ in range(2)]
+            torch.cuda.synchronize()
+            del bufs
+        model, tr, _, batch, nch, _ = bench.build_workload(wl, args, 0, 1, dev)
+        model.current_epoch = tr.current_epoch
+        model.on_train_epoch_start()
+        loss = model.training_step(batch, 0)
+        loss.backward()
+        model.on_after_backward()
+        torch.cuda.synchronize()
+        got = (loss.detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+        if ref is None:
+            ref = got
+        else:
+            assert torch.equal(got[0], ref[0]), (float(got[0]), float(ref[0]), val)
+            bad = [n for n, t in got[1].items() if not torch.equal(t, ref[1][n])]
+            assert not bad, (val, len(bad), bad[:5])
+        del model, tr, batch, got
+        gc.collect()
+        torch.cuda.empty_cache()
+
+
 def test_training_step_with_batchnorm_in_the_head_vs_golden_and_oracle():
     """`method_kwargs.use_bn_in_head = True` (reference src/methods/dino.py:59-77: BatchNorm1d behind the first two Linears of both
     heads): loss, gradients (incl. the BatchNorm scale / shift), the running estimates of both heads after one update per global
