@@ -325,3 +325,19 @@ def test_bench_contract_single_gpu_with_all_legs():
     assert legs["cfg1-graph"]["launch"].startswith("one hipGraph") and legs["cfg1"]["launch"] == "eager"   # (no timing assertions here)
     dp = cfg["data_path"]
     assert "error" not in dp and dp["step_fed_by_pipeline_images_per_s"] > 0 and dp["decode_images_per_s_per_reader_thread"] > 0
+
+
+@pytest.mark.timeout(900)
+def test_example_scripts_run(tmp_path):
+    """examples/pretrain.py (synthetic planes -> device augmentation -> 3 DINO steps -> Lightning-shaped checkpoint + optimiser state)
+    and examples/linear_eval.py on that checkpoint (one epoch, frozen backbone): they run, the loss is finite, the files exist."""
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    ck = str(tmp_path / "pre.ckpt")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "pretrain.py"), "--batch", "8", "--steps", "3", "--local-crops", "2", "--out", ck],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "step 0: loss" in r.stdout and "nan" not in r.stdout.lower() and os.path.isfile(ck) and os.path.isfile(ck + ".optimizer")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "linear_eval.py"), "--ckpt", ck, "--epochs", "1", "--batch", "8"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "epoch 0: train_loss" in r.stdout and "nan" not in r.stdout.lower()
