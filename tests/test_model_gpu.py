@@ -303,6 +303,9 @@ _STEP_CASES = [("step_tiny_multicrop", None, "none"), ("step_tiny_c1_clip", None
                ("step_small_mixed", None, "none"), ("step_small_mixed", 0, "small_fused"), ("step_base_c10", None, "none")]
 
 
+_ORACLE_STEP_CACHE = {}
+
+
 @pytest.mark.parametrize("name,fused_min_rows,dispatch", _STEP_CASES)
 def test_training_step_vs_golden_and_oracle(name, fused_min_rows, dispatch):
     from chadavit_amd import ops
@@ -351,8 +354,15 @@ def test_training_step_vs_golden_and_oracle(name, fused_min_rows, dispatch):
     # ---- loss
     assert abs(loss.item() - float(g["loss"])) <= 2e-2, (loss.item(), float(g["loss"]))
     # ---- gradients vs golden norms and vs oracle tensors
-    loss_o, grads_o, newc_o, aux = R.training_step(sd, crops, ncl, n_large, float(g["teacher_temp"]),
-                                                   freeze_last_layer=epoch < 1, clip_grad=clip)
+    # (the oracle's CPU step is the slow part of this test: computed once per golden and shared by the parametrisations; for the
+    #  26 282-row golden -- two minutes of CPU on a busy box -- only with CHADAVIT_SLOW_TESTS set: its per-tensor gradient NORMS and the
+    #  stored full tensors are held against the golden below either way, and the same dispatch is under the oracle at 600 780 rows in
+    #  test_bench_scale_replicated_batch_vs_golden)
+    grads_o = None
+    if name != "step_tiny_fused_rows" or os.environ.get("CHADAVIT_SLOW_TESTS"):
+        if name not in _ORACLE_STEP_CACHE:
+            _ORACLE_STEP_CACHE[name] = R.training_step(sd, crops, ncl, n_large, float(g["teacher_temp"]), freeze_last_layer=epoch < 1, clip_grad=clip)[1]
+        grads_o = _ORACLE_STEP_CACHE[name]
     named = dict(model.named_parameters())
     none_names = set(str(n) for n in g["none_grad_names"])
     for n in none_names:
@@ -365,6 +375,10 @@ def test_training_step_vs_golden_and_oracle(name, fused_min_rows, dispatch):
         assert gh is not None, n
         tot_h += gh.double().norm().item() ** 2
         tot_r += float(gn) ** 2
+        if grads_o is None:   # per-tensor norm against the golden's instead of the cosine against the oracle's tensor
+            if float(gn) > 1e-3 * float(max(g["grad_norms"])):
+                assert abs(gh.double().norm().item() - float(gn)) <= 6e-2 * float(gn), (n, gh.double().norm().item(), float(gn))
+            continue
         go = grads_o[n]
         if float(gn) > 1e-4 * np.sqrt(go.numel()) * 1e-2:
             c = _cos(gh, go)
