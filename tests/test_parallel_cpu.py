@@ -303,3 +303,63 @@ def test_step_scheduler_and_unknown_scheduler_as_the_reference():
     assert tr.optimizer.param_groups[1]["lr"] == pytest.approx(0.1 * 0.01)    # the classifier group decays with the rest
     with pytest.raises(ValueError):
         Trainer(max_epochs=10, steps_per_epoch=1).attach(DINO(cfg("cosine_restarts")))
+
+
+def test_linear_and_regression_host_logic():
+    """Host-side pieces of the evaluation modules, no GPU: accuracy_at_k / weighted_mean as the reference's (src/utils/metrics.py), the
+    regression metrics against numpy / scipy, the classifier's input width for CLS and all-token features (linear.py:118-138), the
+    scheduler table of configure_optimizers (linear.py:326-369) and the parameter names of both modules' state_dict."""
+    import warnings
+    import numpy as np
+    import pytest
+    import torch
+    from scipy import stats
+    from chadavit_amd.backbones import vit_channels
+    from chadavit_amd.methods.linear import LinearModel, accuracy_at_k, weighted_mean
+    from chadavit_amd.methods.regression import RegressionModel, regression_metrics
+    from chadavit_amd.trainer import Trainer
+    from chadavit_amd.utils.misc import AttrDict
+    from oracle import chada_ref as R
+    g = torch.Generator().manual_seed(0)
+    out, tgt = torch.randn(64, 9, generator=g), torch.randint(0, 9, (64,), generator=g)
+    a1, a5 = accuracy_at_k(out, tgt)
+    assert [float(a1), float(a5)] == pytest.approx(R.accuracy_at_k(out, tgt))
+    assert float(accuracy_at_k(out[:, :3], tgt % 3)[1]) == 100.0          # fewer than five classes: top-5 is everything
+    steps = [{"batch_size": 4, "v": torch.tensor([2.0])}, {"batch_size": 12, "v": torch.tensor([6.0])}]
+    assert float(weighted_mean(steps, "v", "batch_size")) == pytest.approx(5.0)
+    o, t = torch.randn(50, 1, generator=g), torch.randn(50, 1, generator=g)
+    m = regression_metrics(o, t)
+    on, tn = o.view(-1).numpy(), t.view(-1).numpy()
+    assert float(m["mse"]) == pytest.approx(np.mean((on - tn) ** 2), rel=1e-5) and float(m["mae"]) == pytest.approx(np.mean(np.abs(on - tn)), rel=1e-5)
+    assert float(m["pcc"]) == pytest.approx(stats.pearsonr(on, tn)[0], rel=1e-4)
+    assert float(m["r2"]) == pytest.approx(1 - np.sum((on - tn) ** 2) / np.sum((tn - tn.mean()) ** 2), rel=1e-5)
+
+    def cfg(rat, sched="none", opt="sgd", finetune=False):
+        return AttrDict({"backbone": {"name": "vit_channels", "kwargs": {"embed_dim": 192, "patch_size": 16, "return_all_tokens": rat, "max_number_channels": 10}},
+                         "data": {"dataset": "synthetic", "num_classes": 7, "img_channels": 3, "max_img_channels": 10},
+                         "channels_strategy": "multi_channels", "mixed_channels": False, "max_epochs": 10, "finetune": finetune,
+                         "optimizer": {"name": opt, "batch_size": 4, "lr": 0.1, "weight_decay": 0.5},
+                         "scheduler": {"name": sched, "lr_decay_steps": [2, 4]}})
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        bb = vit_channels("dino", patch_size=16, embed_dim=192, return_all_tokens=False, max_number_channels=10)
+        lm = LinearModel(bb, cfg(False))
+        assert lm.classifier.in_features == 192 and not any(p.requires_grad for p in bb.parameters())
+        assert LinearModel(bb, cfg(True)).classifier.in_features == 3 * 196 * 192
+        assert sorted(k for k in lm.state_dict() if not k.startswith("backbone.")) == ["classifier.bias", "classifier.weight"]
+        rm = RegressionModel(bb, cfg(False))
+        assert rm.regressor.out_features == 1 and sorted(k for k in rm.state_dict() if not k.startswith("backbone.")) == ["regressor.bias", "regressor.weight"]
+        assert isinstance(rm.loss_func, torch.nn.MSELoss) and rm.out_layer is rm.regressor
+        for sched, kind in (("none", type(None)), ("step", torch.optim.lr_scheduler.MultiStepLR), ("exponential", torch.optim.lr_scheduler.ExponentialLR),
+                            ("reduce", torch.optim.lr_scheduler.ReduceLROnPlateau), ("warmup_cosine", torch.optim.lr_scheduler.LRScheduler)):
+            tr = Trainer(max_epochs=10, steps_per_epoch=5).attach(LinearModel(bb, cfg(False, sched)))
+            assert isinstance(tr.scheduler, kind), sched
+            assert [len(g_["params"]) for g_ in tr.optimizer.param_groups] == [2]           # the classifier alone
+        tr = Trainer(max_epochs=10, steps_per_epoch=5).attach(LinearModel(bb, cfg(False, "none", "adamw", finetune=True)))
+        assert [g_["name"] for g_ in tr.optimizer.param_groups] == ["backbone", "classifier"]
+        with pytest.raises(ValueError):
+            Trainer(max_epochs=10, steps_per_epoch=5).attach(LinearModel(bb, cfg(False, "cosine_restarts")))
+        bad = cfg(False)
+        bad.optimizer.layer_decay = 0.75
+        with pytest.raises(RuntimeError):
+            LinearModel(bb, bad)
