@@ -8,8 +8,9 @@ launches whose GPU time (~4 ms) is less than half of what the host needs to issu
 What changes from step to step and is NOT frozen into the graph:
   * the crops: copied into static input buffers before each replay (one copy per resolution);
   * the learning rate per param group, Adam's bias corrections, the EMA tau and the teacher temperature: device-resident scalars
-    (`optim.DeviceHyper`, `MomentumUpdater.tau_dev`, `DINOLoss.temp_dev`) filled from a pinned host buffer by the graph's first
-    node; the LR schedule, the tau schedule (momentum.py:76-87) and the step counters keep running on the host exactly as in the
+    (`optim.DeviceHyper`, `MomentumUpdater.tau_dev`, `DINOLoss.temp_dev`) uploaded in front of every replay from a small ring of
+    pinned staging buffers (a staging buffer is rewritten only after the upload that read it has completed, so a host that runs
+    several replays ahead of the GPU cannot overwrite values a queued step has yet to read); the LR schedule, the tau schedule (momentum.py:76-87) and the step counters keep running on the host exactly as in the
     eager loop (base.py:1250-1276 order: optimiser step, then EMA with the CURRENT tau, then the tau update);
   * which parameters receive a gradient (the prototypes are frozen while `epoch < freeze_last_layer`, dino.py:367-376) and the
     channel mix / crop sizes of the batch: part of the signature -- a new signature captures a new graph (kept, keyed; going back
@@ -31,7 +32,7 @@ from .optim import DeviceHyper, FusedAdamW
 class GraphedTrainStep:
     def __init__(self, trainer, warmup: int = 2):
         m = trainer.model
-        if trainer.grad_sync is not None and trainer.grad_sync.reducer.world > 1:
+        if trainer.grad_sync is not None and trainer.grad_sync.reducer.active:
             raise RuntimeError("GraphedTrainStep is single-process (the data-parallel hooks issue collectives from Python)")
         if not isinstance(trainer.optimizer, FusedAdamW):
             raise RuntimeError("GraphedTrainStep needs the fused AdamW (device-resident hyper-parameters)")
@@ -42,8 +43,13 @@ class GraphedTrainStep:
         m.overlap_streams = False                  # one stream: the capture stream
         m.backbone.dw_side_stream = False
         self.hyper = DeviceHyper(self.device)
-        self.extra_host = torch.zeros(2, dtype=torch.float32).pin_memory()   # [tau, teacher temperature]
+        self.extra_host = torch.zeros(2, dtype=torch.float32)                # [tau, teacher temperature]
         self.extra_dev = torch.zeros(2, dtype=torch.float32, device=self.device)
+        # pinned staging ring for the per-step scalars: [hyper slots | tau, temperature] per entry, one event per entry
+        nh = self.hyper.host.numel()
+        self._ring = [(torch.zeros(nh + 2, dtype=torch.float32).pin_memory(), torch.cuda.Event()) for _ in range(4)]
+        self._ring_used = [False] * 4
+        self._ring_next = 0
         self.graphs: Dict[Tuple, Dict[str, Any]] = {}
         self._current = None   # signature of the graph whose slot table / active parameters the DeviceHyper holds
         self._entered = False
@@ -74,8 +80,20 @@ class GraphedTrainStep:
         self.extra_host[1] = float(m.dino_loss_func.teacher_temp_schedule[m.dino_loss_func.epoch])
 
     def _upload_scalars(self):
-        self.hyper.dev.copy_(self.hyper.host, non_blocking=True)
-        self.extra_dev.copy_(self.extra_host, non_blocking=True)
+        """This step's scalars to the device, on the current stream, in front of the step's launches (never inside the graph: a
+        captured copy would read ONE host address whenever the replay gets to it)."""
+        k = self._ring_next
+        self._ring_next = (k + 1) % len(self._ring)
+        stage, ev = self._ring[k]
+        if self._ring_used[k]:
+            ev.synchronize()           # the upload that last read this entry is done (only ever waits when 4 steps ahead)
+        nh = self.hyper.host.numel()
+        stage[:nh].copy_(self.hyper.host)
+        stage[nh:].copy_(self.extra_host)
+        self.hyper.dev.copy_(stage[:nh], non_blocking=True)
+        self.extra_dev.copy_(stage[nh:], non_blocking=True)
+        ev.record()
+        self._ring_used[k] = True
 
     def _snapshot(self):
         """Everything a training step changes, so that the warm-up steps capture needs leave no trace."""
@@ -84,6 +102,9 @@ class GraphedTrainStep:
         flats = [mod.flat_params() for mod in (m.backbone, m.head, m.momentum_backbone, m.momentum_head)]
         dev = [(f, f.flat.clone()) for f in flats]
         dev += [(None, (sl[k], sl[k].clone())) for sl in tr.optimizer._slabs.values() for k in ("m", "v")]
+        # every module buffer: the centre, and with use_bn_in_head the BatchNorm1d running estimates / batch counters of both heads
+        # (ops.bn_stats updates them in place once per crop)
+        dev += [(None, (b, b.clone())) for b in m.buffers()]
         return {"dev": dev, "center": m.dino_loss_func.center.clone(), "global_step": tr.global_step, "last_step": m.last_step,
                 "tau": m.momentum_updater.cur_tau, "lrs": [g["lr"] for g in tr.optimizer.param_groups],
                 "sched": None if tr.scheduler is None else dict(tr.scheduler.state_dict()), "taken": self.hyper.taken}
@@ -193,9 +214,11 @@ class GraphedTrainStep:
             for mod in (m.backbone, m.head, m.momentum_backbone, m.momentum_head):
                 mod.flat_params().mark_dirty()   # the bf16 casts / weight packings of every network must be IN the graph
             g["graph"] = torch.cuda.CUDAGraph()
-            self._fill_scalars()
-            with torch.cuda.graph(g["graph"]):
-                self._upload_scalars()
+            # the graph bakes in the addresses of the ragged index arrays (cu_seqlens, work lists, ...): it owns their descriptions
+            # from here on -- the 8-entry cache of chadavit_amd.ragged may forget them (a validation epoch on other channel mixes)
+            from .ragged import recording_uses
+            g["ragged"] = []
+            with recording_uses(g["ragged"]), torch.cuda.graph(g["graph"]):
                 g["loss"] = self._body(g["batch"], batch_idx)
             self._restore(snap)   # (host-side counters the captured body touched: none today; cheap and safe)
             g["hyper_slots"], g["hyper_active"] = list(self.hyper.slots), list(self.hyper.active)
@@ -205,6 +228,11 @@ class GraphedTrainStep:
             self._current = key
         self._copy_in(g, batch)
         self._fill_scalars()
+        self._upload_scalars()
         g["graph"].replay()
+        # the replay moved the parameters: eager / validation / k-NN passes between replays must re-cast their bf16, packed and MX-fp8
+        # shadows (host-side version bump; the graph itself casts inside)
+        for mod in (m.backbone, m.head, m.momentum_backbone, m.momentum_head):
+            mod.flat_params().mark_dirty()
         self._after_step(batch_idx)
-        return g["loss"]
+        return g["loss"].clone()   # (the graph's loss tensor is rewritten by every replay)

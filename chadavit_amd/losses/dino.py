@@ -69,7 +69,8 @@ class DINOLoss(nn.Module):
             colsum = ops.sum_rows_f32(teacher_output.float().contiguous())
         self.sync_center()
         inv = 1.0 / len(teacher_output)
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        from ..parallel import force_collectives
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force_collectives()):
             inv /= dist.get_world_size()
             if dist.get_backend() == "nccl":
                 main = torch.cuda.current_stream(colsum.device)

@@ -525,22 +525,27 @@ class DINO(_Base):
                 s_local.wait_stream(main)
                 xg.record_stream(s_teacher)
                 with torch.cuda.stream(s_teacher), torch.no_grad():
-                    momentum_p = self._head_per_crop(self.momentum_head, self.momentum_backbone.forward_ragged(xg, nch, rb=rbg), nl)
+                    momentum_feats = self.momentum_backbone.forward_ragged(xg, nch, rb=rbg)
+                    momentum_p = self._head_per_crop(self.momentum_head, momentum_feats, nl)
             feats = self.backbone.forward_ragged(xg, nch, rb=rbg)
             p = self._head_per_crop(self.head, feats, nl)
             feats_list = list(feats.chunk(nl))
             if use_streams:
                 main.wait_stream(s_teacher)
                 momentum_p.record_stream(main)
+                momentum_feats.record_stream(main)
             else:
                 with torch.no_grad():
-                    momentum_p = self._head_per_crop(self.momentum_head, self.momentum_backbone.forward_ragged(xg, nch, rb=rbg), nl)
+                    momentum_feats = self.momentum_backbone.forward_ragged(xg, nch, rb=rbg)
+                    momentum_p = self._head_per_crop(self.momentum_head, momentum_feats, nl)
         else:
             self.head._pending_backwards = nl if (self.head.use_bn and torch.is_grad_enabled()) else 0
             outs = [self(x, k) for k, x in enumerate(X[:nl])]
             p = torch.cat([o["z"] for o in outs])
             feats_list = [o["feats"] for o in outs]
-            momentum_p = torch.cat([self.momentum_forward(x, k)["z"] for k, x in enumerate(X[:nl])])
+            mouts = [self.momentum_forward(x, k) for k, x in enumerate(X[:nl])]
+            momentum_p = torch.cat([o["z"] for o in mouts])
+            momentum_feats = torch.cat([o["feats"] for o in mouts])
         if self.multicrop and self.compute_unused_local_pass:
             # local crops: student backbone only, no head, no loss, no gradient reaches them
             small = list(X[nl:])
@@ -555,7 +560,10 @@ class DINO(_Base):
                 else:
                     feats_list += [self.backbone(x, nl + k, list_num_channels) for k, x in enumerate(small)]
             self._local_pending = use_streams
-        self._last_outs = {"feats": feats_list, "z": p, "momentum_z": momentum_p}
+        # what the passes produced (base.py:1186-1248's `outs`): student CLS features per crop -- global crops, then the local crops the
+        # reference computes and drops --, teacher CLS features, both heads' logits.  The step tests hold every one of them against the
+        # reference (tests/golden_util.py::step_outputs_vs_golden): the loss alone barely moves when a teacher row is wrong.
+        self._last_outs = {"feats": feats_list, "z": p, "momentum_z": momentum_p, "momentum_feats": momentum_feats}
         if self.knn_eval:  # online k-NN bank: CLS features of the global crops with a label (base.py:723-731)
             t_rep = targets.repeat(nl)
             mask = t_rep != -1

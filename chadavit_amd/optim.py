@@ -34,7 +34,16 @@ class DeviceHyper:
         self.taken = 0                 # optimizer steps taken through this object since the last commit
         self.active: List = []         # parameters that are stepped through it (the current graph's)
 
-    def slot(self, gi: int, p, state, optimizer_state) -> torch.Tensor:
+    @staticmethod
+    def _entry(group, t: int):
+        """{lr, 1 - beta1^t, sqrt(1 - beta2^t)} with the same float32 roundings as the by-value path (ops.adamw_step ->
+        chadavit_adamw_step: bias corrections rounded to float32, then sqrtf in float32), so that a replayed step is bit-identical to
+        an eager one."""
+        import numpy as np
+        b1, b2 = group["betas"]
+        return [float(group["lr"]), float(np.float32(1.0 - b1 ** t)), float(np.sqrt(np.float32(1.0 - b2 ** t)))]
+
+    def slot(self, gi: int, p, state, optimizer_state, group=None) -> torch.Tensor:
         step = int(state.get("step", 0))
         i = next((k for k, (g, rep) in enumerate(self.slots) if g == gi and int(optimizer_state[rep].get("step", 0)) == step), None)
         if i is None:
@@ -42,22 +51,26 @@ class DeviceHyper:
                 raise RuntimeError("DeviceHyper: more (group, step count) classes than slots")
             self.slots.append((gi, p))
             i = len(self.slots) - 1
+            if group is not None:
+                # A slot is born inside the optimizer step that first needs it -- AFTER this step's fill() / upload.  It gets its
+                # values here (host entry + a synchronous upload from pageable memory, ordered before the launch that reads it on the
+                # current stream), so that no step ever runs on an unset {lr, bias corrections} = 0 (0 / 0: every parameter NaN).
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("DeviceHyper: a new (group, step count) class appeared during graph capture")
+                vals = self._entry(group, step + self.taken + 1)
+                for k, v in enumerate(vals):
+                    self.host[3 * i + k] = v
+                self.dev[3 * i:3 * i + 3].copy_(torch.tensor(vals, dtype=torch.float32))
         if not any(q is p for q in self.active):
             self.active.append(p)
         return self.dev[3 * i:3 * i + 3]
 
     def fill(self, optimizer) -> None:
-        """Host values for the NEXT step (read by the graph's first node, a copy host -> dev)."""
-        import numpy as np
+        """Host values for the NEXT step (uploaded before the step's launches)."""
         for i, (gi, rep) in enumerate(self.slots):
-            g = optimizer.param_groups[gi]
-            b1, b2 = g["betas"]
             t = int(optimizer.state[rep].get("step", 0)) + self.taken + 1
-            # the same float32 roundings as the by-value path (ops.adamw_step -> chadavit_adamw_step: bias corrections rounded to
-            # float32, then sqrtf in float32), so that a replayed step is bit-identical to an eager one
-            self.host[3 * i] = float(g["lr"])
-            self.host[3 * i + 1] = float(np.float32(1.0 - b1 ** t))
-            self.host[3 * i + 2] = float(np.sqrt(np.float32(1.0 - b2 ** t)))
+            for k, v in enumerate(self._entry(optimizer.param_groups[gi], t)):
+                self.host[3 * i + k] = v
 
     def advance(self) -> None:
         self.taken += 1
@@ -176,7 +189,7 @@ class FusedAdamW(_SlabState, torch.optim.Optimizer):
                 if dh is None:
                     st["step"] = st.get("step", 0) + 1
                 else:
-                    hyper = dh.slot(gi, p, st, self.state)
+                    hyper = dh.slot(gi, p, st, self.state, group)
                 loc = self._where.get(id(p))
                 if loc is None:  # parameter outside the flat slabs (e.g. online classifier if it ever gets a gradient)
                     if "exp_avg" not in st:

@@ -20,6 +20,13 @@ import torch
 import torch.distributed as dist
 
 
+def force_collectives() -> bool:
+    """CHADAVIT_FORCE_COLLECTIVES=1: issue every collective of the data-parallel path even in a process group of ONE rank (they are
+    identities there) -- so that the RCCL code path (ReduceOp.AVG, the communication stream's hand-over, record_stream, the event
+    timing) can be executed on a single-GPU box before the first multi-GPU run (tests/test_ddp_gpu.py)."""
+    return bool(os.environ.get("CHADAVIT_FORCE_COLLECTIVES")) and dist.is_available() and dist.is_initialized()
+
+
 def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     """(rank, world, local_rank) from torchrun's environment; initialises the process group when world > 1.
     backend "nccl" is RCCL on ROCm."""
@@ -30,12 +37,13 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
         local = 0
     if backend is None:
         backend = os.environ.get("CHADAVIT_DIST_BACKEND")
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("CHADAVIT_FORCE_COLLECTIVES")) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     elif torch.cuda.is_available():
         torch.cuda.set_device(local)
@@ -49,6 +57,7 @@ class SpanAllReduce:
     def __init__(self, group=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or force_collectives()
         # RCCL ("nccl") averages in the collective; gloo has no AVG -> SUM then scale
         self.native_avg = dist.is_initialized() and dist.get_backend(group) == "nccl"
         self._stream = None
@@ -69,7 +78,7 @@ class SpanAllReduce:
         return self._stream
 
     def submit(self, flat: torch.Tensor, begin: int, end: int):
-        if self.world == 1 or end <= begin:
+        if not self.active or end <= begin:
             return
         chunk = flat[begin:end]
         self.spans.append((begin, end))
@@ -144,7 +153,7 @@ class GradSync:
 
     def attach(self, model):
         self.model = model
-        if self.reducer.world == 1:
+        if not self.reducer.active:
             return self
         if hasattr(model, "head"):
             if not getattr(model, "batch_crops", False):
@@ -154,7 +163,9 @@ class GradSync:
         else:
             if any(p.requires_grad for p in model.backbone.parameters()):
                 model.backbone.grad_ready_hook = self._hook
-            self._plain = [p for p in getattr(model, "out_layer", model.classifier).parameters() if p.requires_grad]
+            # (RegressionModel deletes `classifier`: a getattr default would evaluate it eagerly and raise)
+            lin = model.out_layer if hasattr(model, "out_layer") else model.classifier
+            self._plain = [p for p in lin.parameters() if p.requires_grad]
         self.broadcast_parameters()
         return self
 

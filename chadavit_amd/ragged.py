@@ -88,6 +88,25 @@ _CACHE: "dict" = {}
 _CACHE_MAX = 8
 
 
+# A captured hipGraph bakes in the device addresses of the index arrays it read: whoever captures must OWN the descriptions for as
+# long as the graph lives (the cache above forgets an entry after eight others).  `recording_uses(lst)` appends every description
+# handed out while it is active to `lst` (chadavit_amd.graphed keeps that list with the graph).
+_RECORDERS: "list" = []
+
+
+class recording_uses:
+    def __init__(self, sink: list):
+        self.sink = sink
+
+    def __enter__(self):
+        _RECORDERS.append(self.sink)
+        return self.sink
+
+    def __exit__(self, *exc):
+        _RECORDERS.remove(self.sink)
+        return False
+
+
 def ragged_batch(num_channels: Sequence[int], patches_per_channel: int, device) -> RaggedBatch:
     key = (tuple(int(c) for c in num_channels), int(patches_per_channel), str(device))
     rb = _CACHE.pop(key, None)
@@ -96,5 +115,8 @@ def ragged_batch(num_channels: Sequence[int], patches_per_channel: int, device) 
         while len(_CACHE) >= _CACHE_MAX:
             _CACHE.pop(next(iter(_CACHE)))
     _CACHE[key] = rb   # most recently used last
+    for sink in _RECORDERS:
+        if not any(r is rb for r in sink):
+            sink.append(rb)
     return rb.use_on_current_stream()
 

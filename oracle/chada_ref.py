@@ -357,7 +357,8 @@ def training_step(sd: Params, crops: List[torch.Tensor], num_channels: List[List
     with torch.no_grad():
         for k in range(num_large_crops, len(crops)):  # local crops: forward only, no loss
             feats.append(fwd(bb, crops[k], num_channels[k], nheads))
-        tz = [head_forward(thd, fwd(tbb, crops[k], num_channels[k], nheads), tbn) for k in range(num_large_crops)]
+        tfeats = [fwd(tbb, crops[k], num_channels[k], nheads) for k in range(num_large_crops)]
+        tz = [head_forward(thd, f, tbn) for f in tfeats]
     p_s = torch.cat(z)
     p_t = torch.cat(tz)
     center = sd["dino_loss_func.center"]
@@ -378,7 +379,10 @@ def training_step(sd: Params, crops: List[torch.Tensor], num_channels: List[List
             g = None
         grads["head." + k] = g
     new_center = center_update(center, p_t)
-    aux = {"student_logits": p_s.detach(), "teacher_logits": p_t, "feats": [f.detach() for f in feats], "head_bn": hbn, "momentum_head_bn": tbn}
+    # what the passes produced (student features of every crop incl. the local ones nobody reads, teacher features, both heads' logits):
+    # pinned to the reference by the step goldens' `outs::*` arrays, and the checker of the HIP path's `DINO._last_outs`
+    aux = {"student_logits": p_s.detach(), "teacher_logits": p_t, "feats": [f.detach() for f in feats], "teacher_feats": tfeats,
+           "head_bn": hbn, "momentum_head_bn": tbn}
     return loss.detach(), grads, new_center, aux
 
 

@@ -80,6 +80,12 @@ def golden_backbone(name, D, nch, sizes, seed_w, seed_x, nheads_direct=None):
     print("wrote", name)
 
 
+def grad_subset_index(numel, k=1024):
+    """Deterministic spread of <= k flat indices of a tensor (first element included); tests/golden_util.py holds the same rule."""
+    k = min(int(numel), k)
+    return (np.arange(k, dtype=np.int64) * int(numel)) // k
+
+
 # --------------------------------------------------------------------------------------
 def build_sd(D, PR, seeds=(1, 2, 3, 4, 5), hidden=2048, bott=256, use_bn=False):
     sd = {}
@@ -116,10 +122,18 @@ def golden_step(name, D, PR, nch, sizes, n_large, epoch, clip_grad=0.0, lr=5e-4,
     for g in params:
         g["params"] = list(g["params"])
     opt = torch.optim.AdamW(params, lr=lr, weight_decay=wd)
+    # Round 4: what the step's passes PRODUCE, not only what the loss and the gradients make of it -- forward hooks (observers; the
+    # reference is not modified) on the four networks record the student's CLS features of every crop (global crops, then the local
+    # crops whose features DINO.training_step computes and drops), the teacher's CLS features and both heads' logits.
+    seen = {"backbone": [], "momentum_backbone": [], "head": [], "momentum_head": []}
+    hooks = [getattr(model, k).register_forward_hook(lambda m_, i_, o_, k=k: seen[k].append(o_.detach().clone())) for k in seen]
     loss = model.training_step(batch, 0)
+    for h in hooks:
+        h.remove()
+    assert len(seen["backbone"]) == len(sizes) and len(seen["momentum_backbone"]) == len(seen["head"]) == len(seen["momentum_head"]) == n_large
     loss.backward()
     model.on_after_backward()
-    names, gnorms, none_names = [], [], []
+    names, gnorms, none_names, gsub = [], [], [], []
     for n, p in model.named_parameters():
         if not n.startswith(("backbone.", "head.", "classifier.")):
             continue
@@ -128,6 +142,7 @@ def golden_step(name, D, PR, nch, sizes, n_large, epoch, clip_grad=0.0, lr=5e-4,
         else:
             names.append(n)
             gnorms.append(p.grad.double().norm().item())
+            gsub.append(f32(p.grad.flatten()[grad_subset_index(p.numel())]))
     out = {"D": D, "P": PR, "nch": np.asarray(nch), "sizes": np.asarray(sizes), "n_large": n_large, "epoch": epoch,
            "clip_grad": clip_grad, "lr": lr, "wd": wd, "base_tau": base_tau, "max_steps": max_steps,
            "teacher_temp": float(model.dino_loss_func.teacher_temp_schedule[epoch]),
@@ -136,6 +151,16 @@ def golden_step(name, D, PR, nch, sizes, n_large, epoch, clip_grad=0.0, lr=5e-4,
            "center_new": f32(model.dino_loss_func.center)[0, :256],
            "center_new_sum": np.float64(model.dino_loss_func.center.double().sum().item()), "use_bn": int(use_bn),
            "norm_last_layer": int(norm_last_layer)}
+    # a fixed spread of <= 1024 elements of EVERY gradient tensor of the reference (grad_subset_index), in the order of grad_names
+    out["gsub_vals"] = np.concatenate(gsub)
+    out["gsub_counts"] = np.asarray([len(v) for v in gsub])
+    for key, mods in (("z", "head"), ("momentum_z", "momentum_head"), ("feats", "backbone"), ("momentum_feats", "momentum_backbone")):
+        t = torch.cat(seen[mods])                                  # crops stacked row-wise, in call order
+        out["outs::" + key] = f32(t if "feats" in key else t[:, :256])   # features: all D columns; logits: the first 256 prototypes
+        out["outs::" + key + "_shape"] = np.asarray(t.shape)
+        out["outs::" + key + "_rowsum"] = t.double().sum(1).numpy()          # fp64 row sums / sums of squares over ALL columns
+        out["outs::" + key + "_rowsq"] = (t.double() ** 2).sum(1).numpy()
+    out["outs::feats_rows_per_crop"] = np.asarray([int(t.shape[0]) for t in seen["backbone"]])
     if not norm_last_layer and dict(model.named_parameters())["head.last_layer.weight_g"].grad is not None:
         out["grad::head.last_layer.weight_g"] = f32(dict(model.named_parameters())["head.last_layer.weight_g"].grad)
     if use_bn:  # the heads' BatchNorm running estimates after the step's forward passes (one update per global crop), and two BN gradients
@@ -492,6 +517,17 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "lars":
         golden_lars("lars")
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "steps_all":
+        # round 4: every step golden again (same arguments as below), now also holding the passes' outputs and a spread of every gradient
+        golden_step("step_tiny_multicrop", 192, 4096, [3, 1, 5], [224, 224, 96, 96], 2, 1)
+        golden_step("step_tiny_c1_clip", 192, 4096, [1, 1, 1, 1], [224, 224], 2, 0, clip_grad=0.3)
+        golden_step("step_small_mixed", 384, 4096, [2, 7, 1], [224, 224, 96, 96], 2, 1)
+        golden_step("step_base_c10", 768, 4096, [10, 3], [224, 224], 2, 1)
+        golden_step("step_tiny_fused_rows", 192, 4096, [10, 10, 10, 10, 10, 8, 5, 3, 1], [224, 224, 96, 96], 2, 1)
+        golden_step("step_tiny_bn_head", 192, 4096, [1, 2, 1, 3, 1, 2, 1, 1, 2, 1, 1, 1, 2, 1, 3, 1], [224, 224, 96], 2, 1, use_bn=True)
+        golden_step("step_tiny_trained_prototype_norms", 192, 4096, [3, 1, 2], [224, 224, 96], 2, 1, norm_last_layer=False)
+        golden_step("step_tiny_trained_prototype_norms_epoch0", 192, 4096, [3, 1, 2], [224, 224, 96], 2, 0, norm_last_layer=False)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "steps_r02":
         # round 2: Small / Base training steps (the D = 384 / 768 backward kernels) and a >= 24576-token Tiny step

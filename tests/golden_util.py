@@ -32,3 +32,109 @@ def ctor_case_state(kw, seed):
     from oracle import procedural as P
     return P.fill_state_dict(P.backbone_shapes(kw["embed_dim"], depth=kw["depth"], patch=kw["patch_size"], img=kw["img_size"][0],
                                                max_channels=kw["max_number_channels"]), seed=seed)
+
+
+def grad_subset_index(numel, k=1024):
+    """The spread of <= k flat indices whose gradient values the step goldens hold for every tensor (`gsub_vals`; same rule as
+    tests/golden/make_golden.py::grad_subset_index)."""
+    import numpy as np
+    k = min(int(numel), k)
+    return (np.arange(k, dtype=np.int64) * int(numel)) // k
+
+
+def golden_grad_subsets(g):
+    """{name: the reference's gradient at grad_subset_index(numel)} from a step golden."""
+    import numpy as np
+    offs = np.concatenate([[0], np.cumsum(g["gsub_counts"])])
+    return {str(n): g["gsub_vals"][offs[i]:offs[i + 1]] for i, n in enumerate(g["grad_names"])}
+
+
+def step_outputs_vs_golden(outs, g, copies=1, cos_min=0.999, rel_max=2e-2, what="HIP"):
+    """What a DINO step's passes produced against the reference's (`outs::*` of a step golden, recorded by forward hooks on the
+    unmodified reference): the student's CLS features of EVERY crop -- the local crops included --, the teacher's CLS features, the
+    student's and the teacher's logits.  `outs` = {"feats": [per crop], "momentum_feats": tensor or None, "z", "momentum_z"}.
+    `copies`: the batch is that many copies of the golden's images, crop by crop (bench-scale replicas): every copy must match.
+    Returns the worst (cosine, rel-L2, name) seen, for the log."""
+    import numpy as np
+    import torch
+
+    def stack(t, rows_per_crop):   # (copies * rows) per crop -> [copy][golden row order]
+        t = t.detach().float().cpu()
+        parts, o = [], 0
+        for r in rows_per_crop:
+            parts.append(t[o:o + r * copies].reshape(copies, r, -1))
+            o += r * copies
+        assert o == t.shape[0], (o, t.shape)
+        return torch.cat(parts, dim=1)
+
+    rpc = [int(v) for v in g["outs::feats_rows_per_crop"]]
+    nl = int(g["n_large"])
+    got = {"feats": stack(torch.cat([f.detach().float().cpu() for f in outs["feats"]]), rpc),
+           "z": stack(outs["z"], rpc[:nl]), "momentum_z": stack(outs["momentum_z"], rpc[:nl])}
+    if outs.get("momentum_feats") is not None:
+        got["momentum_feats"] = stack(outs["momentum_feats"], rpc[:nl])
+    worst = (1.0, 0.0, None)
+    for key, t in got.items():
+        ref = torch.from_numpy(g["outs::" + key]).double()
+        assert list(t.shape[1:]) == [int(v) for v in g["outs::" + key + "_shape"]], (key, t.shape)
+        rs, rq = torch.from_numpy(g["outs::" + key + "_rowsum"]), torch.from_numpy(g["outs::" + key + "_rowsq"])
+        for c in range(copies):
+            h = t[c].double()
+            hh = h[:, :ref.shape[1]]
+            cos = float((hh.flatten() @ ref.flatten()) / (hh.norm() * ref.norm() + 1e-30))
+            rel = float((hh - ref).norm() / (ref.norm() + 1e-30))
+            assert cos >= cos_min and rel <= rel_max, (what, key, "copy", c, "cos", cos, "rel", rel)
+            # every row on its own (one wrong row among many does not move the matrix-level figures much)
+            rrel = (hh - ref).norm(dim=1) / (ref.norm(dim=1) + 1e-30)
+            assert float(rrel.max()) <= 4 * rel_max, (what, key, "copy", c, "row", int(rrel.argmax()), float(rrel.max()))
+            # columns the golden does not hold (logits past the first 256 prototypes): fp64 row sums / sums of squares over all of them
+            # (an element-wise error of relative size r moves a row's sum by ~ r * |row| with random signs, its sum of squares by 2r)
+            assert bool(((h.sum(1) - rs).abs() <= 8 * rel_max * rq.sqrt()).all()), (what, key, "copy", c, "row sums")
+            assert bool((((h ** 2).sum(1) - rq).abs() <= 4 * rel_max * rq).all()), (what, key, "copy", c, "row sums of squares")
+            if cos < worst[0] or rel > worst[1]:
+                worst = (min(cos, worst[0]), max(rel, worst[1]), key)
+    return worst
+
+
+def step_outputs_vs_oracle(outs, aux, copies=1, cos_min=0.999, rel_max=2e-2):
+    """The same four outputs against the CPU oracle's `aux` (oracle/chada_ref.py::training_step), on ALL columns (the golden holds the
+    first 256 prototypes of the logits); `aux` is pinned to the reference by tests/test_oracle_golden.py."""
+    import torch
+    refs = {"feats": list(aux["feats"]), "momentum_feats": list(aux["teacher_feats"]),
+            "z": list(aux["student_logits"].chunk(len(aux["teacher_feats"]))), "momentum_z": list(aux["teacher_logits"].chunk(len(aux["teacher_feats"])))}
+    worst = (1.0, 0.0, None)
+    for key, per_crop in refs.items():
+        got = outs[key]
+        got = torch.cat([f.detach().float().cpu() for f in got]) if isinstance(got, (list, tuple)) else got.detach().float().cpu()
+        ref = torch.cat([r.unsqueeze(0).expand(copies, *r.shape).reshape(-1, r.shape[-1]) for r in per_crop]).double()
+        assert got.shape == ref.shape, (key, got.shape, ref.shape)
+        got = got.double()
+        cos = float((got.flatten() @ ref.flatten()) / (got.norm() * ref.norm() + 1e-30))
+        rel = float((got - ref).norm() / (ref.norm() + 1e-30))
+        rrel = (got - ref).norm(dim=1) / (ref.norm(dim=1) + 1e-30)
+        assert cos >= cos_min and rel <= rel_max, ("vs oracle", key, "cos", cos, "rel", rel)
+        assert float(rrel.max()) <= 4 * rel_max, ("vs oracle", key, "row", int(rrel.argmax()), float(rrel.max()))
+        if cos < worst[0] or rel > worst[1]:
+            worst = (min(cos, worst[0]), max(rel, worst[1]), key)
+    return worst
+
+
+def grad_subsets_vs_golden(named, g, cos_min=0.99, norm_rel=6e-2):
+    """Every gradient tensor of the HIP step against the REFERENCE's own values on the golden's spread of <= 1024 elements per tensor
+    (cosine over the spread; tensors whose norm is negligible beside the largest are skipped, as in the oracle comparison).  Returns
+    the worst (cosine, name)."""
+    import numpy as np
+    worst = (1.0, None)
+    gmax = float(max(g["grad_norms"]))
+    norms = dict(zip([str(n) for n in g["grad_names"]], g["grad_norms"]))
+    for n, ref in golden_grad_subsets(g).items():
+        gh = named[n].grad
+        assert gh is not None, n
+        if float(norms[n]) <= 1e-3 * gmax or float(np.abs(ref).max()) == 0.0:
+            continue
+        got = gh.detach().flatten()[grad_subset_index(gh.numel())].double().cpu().numpy()
+        c = float((got @ ref.astype(np.float64)) / (np.linalg.norm(got) * np.linalg.norm(ref.astype(np.float64)) + 1e-30))
+        if c < worst[0]:
+            worst = (c, n)
+    assert worst[0] >= cos_min, ("gradient spread vs the reference", worst)
+    return worst

@@ -341,3 +341,74 @@ def test_example_scripts_run(tmp_path):
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     assert "epoch 0: train_loss" in r.stdout and "nan" not in r.stdout.lower()
+
+
+RCCL_WORLD1_WORKER = r"""
+import os, sys, json, torch
+sys.path.insert(0, os.environ["CHADAVIT_ROOT"])
+import torch.distributed as dist
+from chadavit_amd.parallel import GradSync, init_from_env, force_collectives
+from chadavit_amd.methods.dino import DINO
+from chadavit_amd.trainer import Trainer
+from chadavit_amd.data.channels_strategies import one_channel_collate_fn
+from oracle import procedural as P
+from tests.golden_util import build_sd
+from tests.test_model_gpu import _cfg
+dev = torch.device("cuda", 0)
+def run(forced):
+    if forced:
+        os.environ["CHADAVIT_FORCE_COLLECTIVES"] = "1"
+        rank, world, local = init_from_env("nccl")          # RCCL, a process group of ONE rank
+        assert dist.is_initialized() and dist.get_backend() == "nccl" and world == 1 and force_collectives()
+    model = DINO(_cfg(192, 4096, 2, 1))
+    model.load_state_dict(build_sd(192, 4096))
+    model = model.to(dev)
+    gs = GradSync() if forced else None
+    tr = Trainer(max_epochs=10, steps_per_epoch=10, grad_sync=gs).attach(model)
+    if forced:
+        assert gs.reducer.active and gs.reducer.native_avg
+        gs.reducer.timing = True
+    tr.current_epoch = 1
+    losses, pend, nspans = [], [], []
+    for step in range(2):
+        crops, labels, ncl = one_channel_collate_fn(P.make_images([3, 1, 2, 1], [224, 224, 96], seed=11 + step))
+        losses.append(tr.train_step(([c.to(dev) for c in crops], labels.to(dev), ncl), 1).item())
+        pend.append(model.dino_loss_func._pending is not None)
+        nspans.append(len(gs.reducer.spans) if forced else 0)
+    torch.cuda.synchronize()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}   # (state_dict finishes the pending centre update)
+    timing = gs.reducer.timing_summary() if forced else None
+    return losses, pend, nspans, sd, timing
+la, pa, na, sda, _ = run(False)
+lb, pb, nb, sdb, timing = run(True)
+same = all(torch.equal(sda[k], sdb[k]) for k in sda)
+diff = [k for k in sda if not torch.equal(sda[k], sdb[k])][:5]
+print("RESULT " + json.dumps({"losses_plain": la, "losses_rccl": lb, "pending_plain": pa, "pending_rccl": pb, "spans": nb, "state_equal": same,
+                              "diff": diff, "timing": timing, "comm_stream": True}), flush=True)
+dist.barrier(); dist.destroy_process_group()
+"""
+
+
+@pytest.mark.timeout(900)
+def test_rccl_code_path_on_one_gpu():
+    """The `nccl` (= RCCL) branches of the data-parallel path -- `SpanAllReduce.submit / finish` on the communication stream with
+    `ReduceOp.AVG`, `DINOLoss.update_center`'s comm-stream all-reduce finished by `sync_center`, `record_stream`, the exposed-time
+    events -- executed on this box's single GPU in a process group of one rank (CHADAVIT_FORCE_COLLECTIVES: the `world == 1`
+    early-outs are skipped; every collective is an identity), so the first multi-GPU run is not also the first RCCL run.  Two
+    training steps with the collectives forced must leave EXACTLY the state of two steps without them (bit for bit: weights, EMA
+    teacher, centre), the centre update must have been in flight when each step returned, and every gradient span must have gone
+    through the reducer."""
+    env_port = socket.socket(); env_port.bind(("127.0.0.1", 0)); port = env_port.getsockname()[1]; env_port.close()
+    env = dict(os.environ, CHADAVIT_ROOT=ROOT, PYTHONPATH=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("CHADAVIT_FORCE_COLLECTIVES", None)
+    r = subprocess.run([sys.executable, "-c", RCCL_WORLD1_WORKER], env=env, capture_output=True, text=True, timeout=800)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
+    assert r.returncode == 0 and lines, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
+    import json
+    out = json.loads(lines[-1][7:])
+    assert out["losses_plain"] == out["losses_rccl"], out
+    assert out["state_equal"], out["diff"]
+    assert out["pending_rccl"] == [True, True] and out["pending_plain"] == [False, False]
+    assert all(n >= 13 for n in out["spans"]), out["spans"]      # 12 blocks' spans (+ embeddings / final norm) + the head
+    assert out["timing"] is not None and out["timing"]["steps"] == 2 and out["timing"]["comm_busy_ms_per_step"] > 0, out["timing"]

@@ -148,6 +148,17 @@ def test_training_step_matches_reference(name):
         if key.startswith("grad::") and not key.endswith("]"):
             np.testing.assert_allclose(grads[key[6:]].numpy(), g[key], rtol=2e-3, atol=3e-6 if "use_bn" in g.files and int(g["use_bn"]) else 3e-7)
     np.testing.assert_allclose(newc[0, :256].numpy(), g["center_new"], atol=1e-7, rtol=0)
+    # round 4: what the passes produced (features of every crop incl. the local ones, teacher features, both heads' logits) and a
+    # spread of <= 1024 elements of EVERY gradient tensor, against the reference's -- this is what pins the oracle's `aux`, the
+    # checker of the HIP path's per-pass outputs in tests/test_model_gpu.py
+    from tests.golden_util import golden_grad_subsets, grad_subset_index, step_outputs_vs_golden
+    step_outputs_vs_golden({"feats": aux["feats"], "momentum_feats": torch.cat(aux["teacher_feats"]), "z": aux["student_logits"],
+                            "momentum_z": aux["teacher_logits"]}, g, cos_min=1 - 1e-7, rel_max=1e-4, what="oracle")
+    bn = "use_bn" in g.files and int(g["use_bn"])
+    for n, ref in golden_grad_subsets(g).items():
+        got = grads[n].flatten()[grad_subset_index(grads[n].numel())].double().numpy()
+        scale = float(np.abs(ref).max())
+        assert float(np.abs(got - ref).max()) <= 2e-3 * scale + (3e-6 if bn else 3e-7), (n, float(np.abs(got - ref).max()), scale)
     for key in g.files:   # use_bn_in_head: the heads' BatchNorm running estimates after one update per global crop
         if key.startswith("bn::"):
             which, rest = key[4:].split(".", 1)
