@@ -17,6 +17,7 @@ training contract needs.  ToGray / Equalize of the reference pipeline require 3-
 """
 from __future__ import annotations
 
+import contextlib
 import math
 import random
 from dataclasses import dataclass, field
@@ -173,10 +174,17 @@ class DeviceMultiCropPipeline:
             p.normalized.append(bool(spec.normalize is not None and self.rng.random() < spec.normalize_prob))
         return p
 
-    def __call__(self, images: Sequence[np.ndarray], labels: Optional[Sequence[int]] = None, params: Optional[List[CropParams]] = None):
+    def __call__(self, images: Sequence[np.ndarray], labels: Optional[Sequence[int]] = None, params: Optional[List[CropParams]] = None,
+                 defer: bool = False):
         """images: per sample a float32 array (C_i, H_i, W_i) (channel planes; sizes may differ between samples).
         Returns what `one_channel_collate_fn` returns for the same batch: (crops, labels, list_num_channels) with
-        crops[k] (sum C, 1, S_k, S_k) fp32 on the device."""
+        crops[k] (sum C, 1, S_k, S_k) fp32 on the device.
+
+        defer = True: only the COPIES happen here (raw planes, descriptor tables -- copy-engine work on whatever stream is current);
+        the crop / blur kernels are handed back as a fourth element `launch(stream)`, to be called once, on the stream that will
+        read the crops, after that stream waits for this call's copies.  `DevicePrefetcher` uses it to run the augmentation kernels
+        at the head of the training step's own stream instead of beside the step on a side stream, where their blocks take CU
+        slots away from kernels that are tuned to fill every one of them."""
         planes = [np.ascontiguousarray(im, dtype=np.float32) for im in images]
         shapes = [tuple(im.shape) for im in planes]
         nch = [s[0] for s in shapes]
@@ -201,7 +209,7 @@ class DeviceMultiCropPipeline:
         if self.device.type == "cuda":
             self._staging_ev[k] = torch.cuda.Event()
             self._staging_ev[k].record(torch.cuda.current_stream(self.device))
-        crops, used = [], []
+        crops, used, pending = [], [], []
         it = iter(params) if params is not None else None
         nchan = sum(nch)
         for spec in self.specs:
@@ -211,17 +219,39 @@ class DeviceMultiCropPipeline:
             for k in range(spec.num_crops):
                 cp = next(it) if it is not None else self._draw(spec, shapes)
                 used.append(cp)
-                crops.append(self._run_crop(spec, cp, src, shapes, offs, out=buf[k * nchan:(k + 1) * nchan]))
+                out = buf[k * nchan:(k + 1) * nchan]
+                prep = self._prepare_crop(spec, cp, shapes, offs)
+                if defer:
+                    pending.append((spec, prep, out))
+                    crops.append(out)
+                else:
+                    crops.append(self._launch_crop(spec, prep, src, out=out))
         self.last_params = used
         lab = torch.as_tensor(list(labels) if labels is not None else [-1] * len(planes), dtype=torch.int64, device=self.device)
-        if len(crops) == 1:   # one_channel_collate_fn returns a bare tensor / list for a single crop (channels_strategies.py:81)
-            return crops[0], lab, nch
-        return crops, lab, [list(nch) for _ in crops]
+        res = (crops[0], lab, nch) if len(crops) == 1 else (crops, lab, [list(nch) for _ in crops])   # (channels_strategies.py:81)
+        if not defer:
+            return res
+
+        def launch(stream=None):
+            """The augmentation kernels, on `stream` (default: the current one), which must already wait for this batch's copies."""
+            cur = torch.cuda.current_stream(self.device) if stream is None else stream
+            if src.is_cuda:   # allocated and filled on the producer's stream, read here
+                src.record_stream(cur)
+                for _, prep_, _ in pending:
+                    for t_ in prep_["device_tensors"]:
+                        t_.record_stream(cur)
+            with (torch.cuda.stream(cur) if src.is_cuda else contextlib.nullcontext()):
+                for spec_, prep_, out_ in pending:
+                    self._launch_crop(spec_, prep_, src, out=out_)
+            pending.clear()
+        return res + (launch,)
 
     def _run_crop(self, spec: CropSpec, cp: CropParams, src, shapes, offs, out=None) -> torch.Tensor:
+        return self._launch_crop(spec, self._prepare_crop(spec, cp, shapes, offs), src, out=out)
+
+    def _prepare_crop(self, spec: CropSpec, cp: CropParams, shapes, offs) -> dict:
         """Per-channel-image descriptor tables for the two kernels, built with numpy (a Python loop over the ~1500 channel images of
-        a 512-image batch, ten crops per batch, was the slowest stage of the whole data path)."""
-        S = spec.crop_size
+        a 512-image batch, ten crops per batch, was the slowest stage of the whole data path) and uploaded: host work + copies only."""
         n = len(shapes)
         C = np.fromiter((s_[0] for s_ in shapes), dtype=np.int64, count=n)
         H = np.fromiter((s_[1] for s_ in shapes), dtype=np.int64, count=n)
@@ -239,25 +269,12 @@ class DeviceMultiCropPipeline:
         desc = np.stack([rep(off) + chan * rep(H * W), rep(H), rep(W), rep(box[:, 1]), rep(box[:, 0]), rep(box[:, 3]), rep(box[:, 2]),
                          rep(np.asarray(cp.flips, dtype=np.int64))], axis=1)
         dev = self.device
-        d = torch.from_numpy(desc).to(dev, non_blocking=True)
-        first = None if any_fin else out   # the finishing pass reads the resized planes and writes the caller's buffer
+        prep = {"grays": grays if any(grays) else None, "C": C, "n": n, "shift": None, "gamma": None, "fin": None}
+        prep["d"] = torch.from_numpy(desc).to(dev, non_blocking=True)
         if any_jit:   # gamma = -1 marks the channel images whose sample did not draw the jitter (no clamp for them)
             shift = np.concatenate([np.zeros(c, np.float32) if s_ is None else np.asarray(s_, np.float32) for c, s_ in zip(C, cp.shifts)])
             gamma = np.concatenate([np.full(c, -1.0, np.float32) if g_ is None else np.asarray(g_, np.float32) for c, g_ in zip(C, cp.gammas)])
-            res = ops.crop_resize(src, d, S, torch.from_numpy(shift).to(dev, non_blocking=True), torch.from_numpy(gamma).to(dev, non_blocking=True),
-                                  out=first)
-        else:
-            res = ops.crop_resize(src, d, S, out=first)
-        if any(grays):
-            # A.ToGray on the (rare) 3-channel samples that drew it: cv2 RGB2GRAY weights, replicated to the three planes
-            # (albumentations functional.to_gray).  Sits between the jitter and the blur as in the reference's list; it commutes
-            # with the flip fused into the resize pass.  Plain tensor arithmetic on three planes per firing sample.
-            w = torch.tensor([0.299, 0.587, 0.114], device=dev, dtype=torch.float32).view(3, 1, 1, 1)
-            c0 = 0
-            for i in range(n):
-                if grays[i]:
-                    res[c0:c0 + 3] = (res[c0:c0 + 3] * w).sum(0, keepdim=True)
-                c0 += int(C[i])
+            prep["shift"], prep["gamma"] = torch.from_numpy(shift).to(dev, non_blocking=True), torch.from_numpy(gamma).to(dev, non_blocking=True)
         if any_fin:
             fin = np.zeros((int(C.sum()), 12), dtype=np.float32)
             fin[:, 8] = np.inf
@@ -280,5 +297,27 @@ class DeviceMultiCropPipeline:
                 on = rep(normed)
                 fin[on, 10] = (mean[chan % len(mean)] * mpv)[on]
                 fin[on, 11] = (1.0 / (std[chan % len(std)] * mpv))[on]
-            res = ops.blur_finish(res, torch.from_numpy(fin).to(dev, non_blocking=True), out=out)
+            prep["fin"] = torch.from_numpy(fin).to(dev, non_blocking=True)
+        prep["device_tensors"] = [t_ for t_ in (prep["d"], prep["shift"], prep["gamma"], prep["fin"]) if t_ is not None and t_.is_cuda]
+        return prep
+
+    def _launch_crop(self, spec: CropSpec, prep: dict, src, out=None) -> torch.Tensor:
+        """The kernels of one crop on the current stream: resize (+ jitter, flip), optional ToGray, optional blur / solarize / normalise."""
+        first = None if prep["fin"] is not None else out   # the finishing pass reads the resized planes and writes the caller's buffer
+        if prep["shift"] is not None:
+            res = ops.crop_resize(src, prep["d"], spec.crop_size, prep["shift"], prep["gamma"], out=first)
+        else:
+            res = ops.crop_resize(src, prep["d"], spec.crop_size, out=first)
+        if prep["grays"] is not None:
+            # A.ToGray on the (rare) 3-channel samples that drew it: cv2 RGB2GRAY weights, replicated to the three planes
+            # (albumentations functional.to_gray).  Sits between the jitter and the blur as in the reference's list; it commutes
+            # with the flip fused into the resize pass.  Plain tensor arithmetic on three planes per firing sample.
+            w = torch.tensor([0.299, 0.587, 0.114], device=self.device, dtype=torch.float32).view(3, 1, 1, 1)
+            c0 = 0
+            for i in range(prep["n"]):
+                if prep["grays"][i]:
+                    res[c0:c0 + 3] = (res[c0:c0 + 3] * w).sum(0, keepdim=True)
+                c0 += int(prep["C"][i])
+        if prep["fin"] is not None:
+            res = ops.blur_finish(res, prep["fin"], out=out)
         return res

@@ -3,9 +3,12 @@ kernels on a SIDE HIP stream, `depth` batches ahead of the training step.
 
 The reference feeds its step from `DataLoader(dataset, collate_fn=one_channel_collate_fn, num_workers=...)`
 (pretrain_dataloader.py:517-525): worker processes decode the channel files and run the albumentations chain on the CPU.
-Here the workers only DECODE (`dataset.read_planes`, PIL releases the GIL); everything after that -- the copy of the raw planes and
-the crop / jitter / blur kernels of `DeviceMultiCropPipeline` -- runs on the GPU, on a stream of its own, while the previous step
-computes.  The consumer orders itself behind a batch with one event wait; nothing blocks the host.
+Here the workers only DECODE (`dataset.read_planes`, PIL releases the GIL); everything after that runs on the GPU: the copies of
+the raw planes and of the per-crop descriptor tables on a stream of their own (copy engine), `depth` batches ahead, and the crop /
+jitter / blur kernels of `DeviceMultiCropPipeline` at the head of the CONSUMER's stream when the batch is handed over
+(`kernels_on="consumer"`, round 4: launched beside the step on the side stream, `kernels_on="producer"`, their blocks take CU slots
+from kernels tuned to fill all of them -- the fed step lost 5-8 % to ~2 ms of augmentation work).  The consumer orders itself
+behind a batch's copies with one event wait; nothing blocks the host.
 
     ds = IDRCell100K(root_dir=..., train=True)
     sampler = TokenBalancedBatchSampler(ds.num_channels(), global_batch, rank, world)
@@ -25,7 +28,10 @@ import torch
 
 class DevicePrefetcher:
     def __init__(self, dataset, batch_sampler: Iterable[Sequence[int]], pipeline, depth: int = 2, workers: int = 8,
-                 labels: Optional[Sequence[int]] = None):
+                 labels: Optional[Sequence[int]] = None, kernels_on: str = "consumer"):
+        if kernels_on not in ("consumer", "producer"):
+            raise ValueError("kernels_on: 'consumer' or 'producer'")
+        self.defer = kernels_on == "consumer" and pipeline.device.type == "cuda"
         self.dataset, self.batch_sampler, self.pipeline = dataset, batch_sampler, pipeline
         self.depth, self.workers, self.labels = max(1, depth), max(1, workers), labels
         self.device = pipeline.device
@@ -49,15 +55,18 @@ class DevicePrefetcher:
                     planes = list(pool.map(self.dataset.read_planes, idx))
                     self.read_s += time.perf_counter() - t0
                     labs = [self.labels[i] for i in idx] if self.labels is not None else None
+                    launch = None
                     if self.stream is not None:
                         with torch.cuda.stream(self.stream):
-                            batch = self.pipeline(planes, labels=labs)
+                            batch = self.pipeline(planes, labels=labs, defer=self.defer)
+                            if self.defer:
+                                batch, launch = batch[:-1], batch[-1]
                             ev = torch.cuda.Event()
                             ev.record(self.stream)
                     else:
                         batch, ev = self.pipeline(planes, labels=labs), None
                     self.batches += 1
-                    q.put((batch, ev))
+                    q.put((batch, ev, launch))
             q.put(None)
         except BaseException as e:  # noqa: BLE001 - handed to the consumer
             q.put(e)
@@ -74,7 +83,7 @@ class DevicePrefetcher:
                     break
                 if isinstance(item, BaseException):
                     raise item
-                batch, ev = item
+                batch, ev, launch = item
                 if ev is not None:
                     cur = torch.cuda.current_stream(self.device)
                     cur.wait_event(ev)
@@ -82,6 +91,8 @@ class DevicePrefetcher:
                     for c in crops:   # allocated on the side stream, consumed on this one
                         c.record_stream(cur)
                     batch[1].record_stream(cur)
+                    if launch is not None:
+                        launch(cur)   # the augmentation kernels, in front of the step that reads their output
                 yield batch
         finally:
             stop.set()
