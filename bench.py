@@ -678,7 +678,7 @@ def data_path_leg(wl, args, dev, tr, steps=6, n_samples=1536, side=256, workers=
         specs.append(CropSpec(crop_size=96, num_crops=wl["n_local"], crop_min_scale=0.05, crop_max_scale=0.25, jitter_prob=0.8, blur_prob=0.5, flip_prob=0.5))
     batches = [list(range(i, i + B)) for i in range(0, n_samples - B + 1, B)]
 
-    def loader(kernels_on="consumer"):
+    def loader(kernels_on="producer"):
         return DevicePrefetcher(ds, batches * ((steps + 2 + len(batches) - 1) // len(batches)), DeviceMultiCropPipeline(specs, dev, seed=1), depth=2,
                                 workers=workers, kernels_on=kernels_on)
 
@@ -696,7 +696,7 @@ def data_path_leg(wl, args, dev, tr, steps=6, n_samples=1536, side=256, workers=
     torch.cuda.synchronize()
     pipe_ips = (n - B) / (time.perf_counter() - t0) if n > B else None
     # (b) the training step fed by it (the global crops arrive as two specs: adjacent_view falls back to one torch.cat): with the
-    # augmentation kernels at the head of the step's own stream (the default), and beside the step on the prefetcher's side stream
+    # augmentation kernels beside the step on the prefetcher's side stream (the default), and at the head of the step's own stream
     def fed(kernels_on):
         n = 0
         for i, batch in enumerate(loader(kernels_on)):
@@ -709,8 +709,8 @@ def data_path_leg(wl, args, dev, tr, steps=6, n_samples=1536, side=256, workers=
                 break
         torch.cuda.synchronize()
         return n / (time.perf_counter() - t0)
-    step_ips = fed("consumer")
-    step_ips_side = fed("producer")
+    step_ips = fed("producer")
+    step_ips_main = fed("consumer")
     # ... and the same steps on ONE resident batch right after, same clocks (the headline ran minutes earlier)
     one = next(iter(loader()))
     for i in range(2):
@@ -742,7 +742,7 @@ def data_path_leg(wl, args, dev, tr, steps=6, n_samples=1536, side=256, workers=
     return {"what": "reader threads -> pinned staging ring -> H2D -> chadavit_crop_resize / chadavit_blur_finish on a side stream (DevicePrefetcher), "
                     "synthetic decoded planes in host memory", "raw_plane_side": side, "raw_MB_per_image": round(raw_mb, 2), "reader_threads": workers,
             "pipeline_alone_images_per_s": None if pipe_ips is None else round(pipe_ips, 1), "step_fed_by_pipeline_images_per_s": round(step_ips, 1),
-            "step_fed_with_augmentation_kernels_on_the_side_stream_images_per_s": round(step_ips_side, 1),
+            "step_fed_with_augmentation_kernels_on_the_steps_own_stream_images_per_s": round(step_ips_main, 1),
             "same_steps_on_one_resident_batch_images_per_s": round(resident_ips, 1), "fed_over_resident": round(step_ips / resident_ips, 4),
             "h2d_GBps_at_that_rate": round(step_ips * raw_mb / 1e3, 2),
             "decode_images_per_s_per_reader_thread": round(decode_ips, 1), "decode_format": f"3 x {side}x{side} 8-bit PNG per image (PIL)",

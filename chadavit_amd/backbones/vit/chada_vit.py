@@ -101,6 +101,9 @@ class ChAdaViT(nn.Module):
         self._tn_ws: Optional[torch.Tensor] = None
         self._ln_ws: Optional[torch.Tensor] = None
         self.grad_ready_hook = None  # callable(flat, begin, end) fired as each slab of gradients completes
+        # > 1: that many backward passes of this step accumulate into the gradient slab (DINO's standard_multicrop_loss option: the
+        # global-crop and the local-crop pass); the spans are final -- and the hook fires -- during the LAST of them
+        self._pending_backwards = 0
         # weight-gradient GEMMs on a second HIP stream beside the dX chain.  Default by measurement (round 2, same box, img/s
         # overlapped vs one stream): Base 150.4 vs 145.4 -- its GEMM-chain kernels leave grid tails the side stream fills;
         # Tiny 4469 vs 4540, Small 1087 vs 1084, the 4-image reference config 386 vs 428 -- the fused block kernels fill the
@@ -623,6 +626,11 @@ class _BackboneFn(torch.autograd.Function):
             dx = ops.layernorm_bwd(dfull, xlast, st[0], st[1], flat.f("norm.weight"), G("norm.weight"), G("norm.bias"), ln_ws,
                                    accumulate=acc)
         hook = m.grad_ready_hook
+        if m._pending_backwards > 1:   # an earlier pass of several: nothing is final yet
+            m._pending_backwards -= 1
+            hook = None
+        else:
+            m._pending_backwards = 0
         if hook is not None:
             hook(flat, *flat.span(["norm.weight", "norm.bias"]))
         main = torch.cuda.current_stream(dev)

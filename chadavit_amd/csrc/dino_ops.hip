@@ -146,6 +146,60 @@ __global__ __launch_bounds__(256) void dino_loss_kernel(const float* __restrict_
   if (tid == 0) loss_rows[b] = 0.5f * acc;
 }
 
+// ---- the same loss over V >= 2 student views (losses/dino.py:69-100 with `student_out.chunk(V)`: every teacher view iq < 2 against
+// every student view v != iq, 2 V - 2 terms, mean): the standard-DINO multi-crop form, in which the local crops go through the head
+// and reach the loss.  The reference's DINO never feeds them (its multicrop_forward returns backbone features only), so this is a
+// separately flagged option, not the parity path; V = 2 is dino_loss_kernel's arithmetic.  Rows: student[v * B + b], teacher[iq * B + b].
+// One block per image: teacher statistics once, then per student view its statistics and one pass for the loss terms and dL/ds_v
+// (the teacher probabilities are recomputed from the logits: P floats x 2 do not fit LDS at P = 65536).
+__global__ __launch_bounds__(256) void dino_loss_mc_kernel(const float* __restrict__ student, const float* __restrict__ teacher,
+                                                           const float* __restrict__ center, float inv_ts, float inv_tt,
+                                                           float* __restrict__ loss_rows, bf16_t* __restrict__ dstudent, int B, int V,
+                                                           int P) {
+  __shared__ float red[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* t0 = teacher + (size_t)b * P;
+  const float* t1 = teacher + (size_t)(B + b) * P;
+  float mt0 = -INFINITY, mt1 = -INFINITY;
+  for (int c = tid; c < P; c += 256) {
+    const float cc = center[c];
+    mt0 = fmaxf(mt0, (t0[c] - cc) * inv_tt);
+    mt1 = fmaxf(mt1, (t1[c] - cc) * inv_tt);
+  }
+  mt0 = block_max(mt0, red); mt1 = block_max(mt1, red);
+  float zt0 = 0.f, zt1 = 0.f;
+  for (int c = tid; c < P; c += 256) {
+    const float cc = center[c];
+    zt0 += expf((t0[c] - cc) * inv_tt - mt0);
+    zt1 += expf((t1[c] - cc) * inv_tt - mt1);
+  }
+  zt0 = block_sum(zt0, red); zt1 = block_sum(zt1, red);
+  const float izt0 = 1.0f / zt0, izt1 = 1.0f / zt1;
+  const float inv_terms = 1.0f / (float)(2 * V - 2);
+  const float gscale = inv_terms * inv_ts / (float)B;
+  float acc = 0.f;
+  for (int v = 0; v < V; ++v) {
+    const float* sv = student + (size_t)(v * B + b) * P;
+    float ms = -INFINITY;
+    for (int c = tid; c < P; c += 256) ms = fmaxf(ms, sv[c] * inv_ts);
+    ms = block_max(ms, red);
+    float zs = 0.f;
+    for (int c = tid; c < P; c += 256) zs += expf(sv[c] * inv_ts - ms);
+    zs = block_sum(zs, red);
+    const float lzs = logf(zs), izs = 1.0f / zs;
+    const float w0 = (v == 0) ? 0.f : 1.f, w1 = (v == 1) ? 0.f : 1.f;   // teacher view iq pairs with every student view but its own
+    for (int c = tid; c < P; c += 256) {
+      const float cc = center[c];
+      const float a = sv[c] * inv_ts - ms;
+      const float q = w0 * expf((t0[c] - cc) * inv_tt - mt0) * izt0 + w1 * expf((t1[c] - cc) * inv_tt - mt1) * izt1;
+      acc -= q * (a - lzs);
+      if (dstudent) dstudent[(size_t)(v * B + b) * P + c] = (bf16_t)(((w0 + w1) * expf(a) * izs - q) * gscale);
+    }
+  }
+  acc = block_sum(acc, red);
+  if (tid == 0) loss_rows[b] = acc * inv_terms;
+}
+
 // Column sums of a row-major [rows, cols] fp32 matrix (the centre's teacher-logit sum, losses/dino.py:106).  One block owns 64
 // columns: 16 lanes x float4 = one 256-byte row segment per row group, 16 row groups per block each summing every 16th row
 // with eight independent loads in flight, then a fixed-order LDS reduction over the row groups (deterministic; no atomics, no
@@ -608,6 +662,20 @@ extern "C" int chadavit_dino_loss(const float* student, const float* teacher, co
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(dino_loss_kernel, dim3(B), dim3(256), 0, s, student, teacher, center, 1.0f / student_temp,
                      1.0f / teacher_temp, loss_rows, reinterpret_cast<bf16_t*>(dstudent), B, P, (const float*)nullptr);
+  if (teacher_colsum)
+    hipLaunchKernelGGL(sum_rows_kernel, dim3((P + 63) / 64), dim3(256), 0, s, teacher, teacher_colsum, 2 * B, P, 1.0f,
+                       (int)((P & 3) == 0 && ((uintptr_t)teacher & 15) == 0));
+  CHADA_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int chadavit_dino_loss_multicrop(const float* student, const float* teacher, const float* center, float student_temp,
+                                            float teacher_temp, float* loss_rows, chada_bf16* dstudent, float* teacher_colsum, int B,
+                                            int V, int P, void* stream) {
+  CHADA_ENTRY();
+  if (!student || !teacher || !center || !loss_rows || B <= 0 || V < 2 || P <= 0 || student_temp <= 0.f || teacher_temp <= 0.f) return 1;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(dino_loss_mc_kernel, dim3(B), dim3(256), 0, s, student, teacher, center, 1.0f / student_temp, 1.0f / teacher_temp,
+                     loss_rows, reinterpret_cast<bf16_t*>(dstudent), B, V, P);
   if (teacher_colsum)
     hipLaunchKernelGGL(sum_rows_kernel, dim3((P + 63) / 64), dim3(256), 0, s, teacher, teacher_colsum, 2 * B, P, 1.0f,
                        (int)((P & 3) == 0 && ((uintptr_t)teacher & 15) == 0));

@@ -3,12 +3,12 @@ kernels on a SIDE HIP stream, `depth` batches ahead of the training step.
 
 The reference feeds its step from `DataLoader(dataset, collate_fn=one_channel_collate_fn, num_workers=...)`
 (pretrain_dataloader.py:517-525): worker processes decode the channel files and run the albumentations chain on the CPU.
-Here the workers only DECODE (`dataset.read_planes`, PIL releases the GIL); everything after that runs on the GPU: the copies of
-the raw planes and of the per-crop descriptor tables on a stream of their own (copy engine), `depth` batches ahead, and the crop /
-jitter / blur kernels of `DeviceMultiCropPipeline` at the head of the CONSUMER's stream when the batch is handed over
-(`kernels_on="consumer"`, round 4: launched beside the step on the side stream, `kernels_on="producer"`, their blocks take CU slots
-from kernels tuned to fill all of them -- the fed step lost 5-8 % to ~2 ms of augmentation work).  The consumer orders itself
-behind a batch's copies with one event wait; nothing blocks the host.
+Here the workers only DECODE (`dataset.read_planes`, PIL releases the GIL); everything after that -- the copy of the raw planes and
+the crop / jitter / blur kernels of `DeviceMultiCropPipeline` -- runs on the GPU, on a stream of its own, `depth` batches ahead, while
+the previous step computes.  The consumer orders itself behind a batch with one event wait; nothing blocks the host.
+`kernels_on="consumer"` moves the augmentation KERNELS (not the copies) to the head of the consumer's stream instead -- measured in
+round 4 and not the default: the cfg2 step fed that way ran at 0.928 of the same steps on a resident batch, against 0.967 with the kernels
+beside the step on the side stream (they take ~7 ms serial per 512-image batch and mostly fit into the step's own slack).
 
     ds = IDRCell100K(root_dir=..., train=True)
     sampler = TokenBalancedBatchSampler(ds.num_channels(), global_batch, rank, world)
@@ -28,7 +28,7 @@ import torch
 
 class DevicePrefetcher:
     def __init__(self, dataset, batch_sampler: Iterable[Sequence[int]], pipeline, depth: int = 2, workers: int = 8,
-                 labels: Optional[Sequence[int]] = None, kernels_on: str = "consumer"):
+                 labels: Optional[Sequence[int]] = None, kernels_on: str = "producer"):
         if kernels_on not in ("consumer", "producer"):
             raise ValueError("kernels_on: 'consumer' or 'producer'")
         self.defer = kernels_on == "consumer" and pipeline.device.type == "cuda"

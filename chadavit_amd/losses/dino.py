@@ -37,9 +37,12 @@ class DINOLoss(nn.Module):
         self.epoch = 0
         self.student_temp = student_temp
         self.center_momentum = center_momentum
+        # `num_large_crops` = the number of views the STUDENT's logits are chunked into (losses/dino.py:82, the reference's name).  The
+        # reference's DINO always leaves it at 2 (dino.py:171-178: only the global crops reach the loss); a larger value is the
+        # standard-DINO multi-crop loss over 2 teacher x V student views, DINO's `method_kwargs.standard_multicrop_loss` option.
         self.num_large_crops = num_large_crops
-        if num_large_crops != 2:
-            raise RuntimeError("DINOLoss: the reference loss is defined over exactly 2 global views (losses/dino.py:87)")
+        if num_large_crops < 2:
+            raise RuntimeError("DINOLoss: at least the 2 global views (the teacher's, losses/dino.py:87) must reach the loss")
         self.register_buffer("center", torch.zeros(1, num_prototypes))
         self.temp_dev = None
         self._pending = None       # (event | work, column sum, 1 / (world * rows)) of a centre update in flight
@@ -52,6 +55,9 @@ class DINOLoss(nn.Module):
         # temp_dev: a device float32[1] holding the teacher temperature of this epoch (chadavit_amd.graphed: the captured step reads
         # it from memory instead of freezing the value into the graph)
         temp = self.temp_dev if self.temp_dev is not None else float(self.teacher_temp_schedule[self.epoch])
+        if student_output.shape[0] * 2 != teacher_output.shape[0] * self.num_large_crops:
+            raise RuntimeError(f"DINOLoss: {student_output.shape[0]} student rows are not {self.num_large_crops} views of the "
+                               f"{teacher_output.shape[0] // 2} images the teacher saw")
         self.sync_center()  # the previous step's centre update (its all-reduce ran beside that step's backward)
         loss, colsum = _DinoLossFn.apply(student_output, teacher_output, self.center, float(self.student_temp), temp)
         self.update_center(teacher_output, colsum)

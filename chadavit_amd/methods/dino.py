@@ -328,9 +328,15 @@ class DINO(_Base):
         self.head = DINOHead(**head_kw)
         self.momentum_head = DINOHead(**head_kw)
         initialize_momentum_params(self.head, self.momentum_head)
+        # Build-side option, OFF by default (not a reference key; SURVEY 7 / 8(d) "standard-DINO"): the multi-crop loss of the DINO paper --
+        # the local crops go through the head, reach the loss as extra student views (2 teacher x (2 + n_local) student pairs) and are
+        # trained through.  The reference computes the local crops' backbone features and drops them (dino.py:300-325; base.py:566-620
+        # returns no "z"); parity mode reproduces exactly that.
+        self.standard_multicrop_loss = bool(mk.standard_multicrop_loss) and self.multicrop
         self.dino_loss_func = DINOLoss(num_prototypes=mk.num_prototypes, student_temp=mk.student_temperature,
                                        warmup_teacher_temp=mk.warmup_teacher_temperature, teacher_temp=mk.teacher_temperature,
-                                       warmup_teacher_temp_epochs=mk.warmup_teacher_temperature_epochs, num_epochs=self.max_epochs)
+                                       warmup_teacher_temp_epochs=mk.warmup_teacher_temperature_epochs, num_epochs=self.max_epochs,
+                                       num_large_crops=self.num_crops if self.standard_multicrop_loss else 2)
         self.last_step = 0
         # ---- validation pieces (base.py:277-296): online k-NN bank, per-batch metric list, SSL validation loss switch
         self.knn_eval = cfg.knn_eval.enabled
@@ -392,6 +398,7 @@ class DINO(_Base):
         mk.freeze_last_layer = omegaconf_select(cfg, "method_kwargs.freeze_last_layer", 1)
         mk.norm_last_layer = omegaconf_select(cfg, "method_kwargs.norm_last_layer", True)
         mk.use_bn_in_head = omegaconf_select(cfg, "method_kwargs.use_bn_in_head", False)
+        mk.standard_multicrop_loss = omegaconf_select(cfg, "method_kwargs.standard_multicrop_loss", False)
         mk.student_temperature = omegaconf_select(cfg, "method_kwargs.student_temperature", 0.1)
         mk.teacher_temperature = omegaconf_select(cfg, "method_kwargs.teacher_temperature", 0.07)
         mk.warmup_teacher_temperature = omegaconf_select(cfg, "method_kwargs.warmup_teacher_temperature", 0.04)
@@ -546,7 +553,23 @@ class DINO(_Base):
             mouts = [self.momentum_forward(x, k) for k, x in enumerate(X[:nl])]
             momentum_p = torch.cat([o["z"] for o in mouts])
             momentum_feats = torch.cat([o["feats"] for o in mouts])
-        if self.multicrop and self.compute_unused_local_pass:
+        if self.multicrop and self.standard_multicrop_loss:
+            # standard-DINO option: the local crops are student views like the global ones -- backbone WITH gradient, head, loss
+            small = list(X[nl:])
+            if not (self.batch_crops and all(x.shape[-1] == small[0].shape[-1] for x in small)) or self.head.use_bn:
+                raise RuntimeError("standard_multicrop_loss: local crops of one size, batch_crops=True and no BatchNorm in the head")
+            xs = adjacent_view(small)
+            if xs is None:
+                xs = torch.cat(small, dim=0)
+            nchs = [c for k in range(len(small)) for c in list_num_channels[nl + k]]
+            if torch.is_grad_enabled():   # two backward passes per network this step: the gradient spans are final after the second
+                self.backbone._pending_backwards = 2
+                self.head._pending_backwards = 2
+            feats_l = self.backbone.forward_ragged(xs, nchs)
+            p = torch.cat([p, self.head(feats_l)])
+            feats_list += list(feats_l.chunk(len(small)))
+            self._local_pending = False
+        elif self.multicrop and self.compute_unused_local_pass:
             # local crops: student backbone only, no head, no loss, no gradient reaches them
             small = list(X[nl:])
             ctx = torch.cuda.stream(s_local) if use_streams else torch.no_grad()

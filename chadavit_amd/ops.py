@@ -625,15 +625,26 @@ def weightnorm_bwd(dw, v, g, inv, dv, accumulate=False, dg=None):
 
 
 def dino_loss(student, teacher, center, student_temp, teacher_temp, want_grad=True):
-    """Returns (loss_rows [B], dstudent bf16 [2B,P] | None, teacher_colsum [P]).  teacher_temp: a float, or a device float32[1]
-    tensor (read by the kernel: graph-captured training step)."""
+    """Returns (loss_rows [B], dstudent bf16 [V B,P] | None, teacher_colsum [P]).  teacher_temp: a float, or a device float32[1]
+    tensor (read by the kernel: graph-captured training step).  student [V B, P] with V = 2 (the reference's DINO: global crops only)
+    or V > 2 (standard-DINO multi-crop option: the local crops' logits follow the two global views)."""
     _req(student, F32, "student"); _req(teacher, F32, "teacher"); _req(center, F32, "center")
     B2, P = student.shape
-    B = B2 // 2
+    B = teacher.shape[0] // 2
+    if teacher.shape[0] != 2 * B or B2 % B != 0 or B2 < 2 * B:
+        raise RuntimeError(f"dino_loss: student rows {B2} are not a whole number (>= 2) of views of the teacher's {B} images")
+    V = B2 // B
     dev = student.device
     loss_rows = torch.empty((B,), device=dev, dtype=F32)
     dstudent = torch.empty((B2, P), device=dev, dtype=BF16) if want_grad else None
     colsum = torch.empty((P,), device=dev, dtype=F32)
+    if V > 2:
+        if isinstance(teacher_temp, torch.Tensor):
+            raise RuntimeError("dino_loss: the multi-crop form takes the teacher temperature by value (not captured in hipGraphs)")
+        rc = lib().chadavit_dino_loss_multicrop(_ptr(student), _ptr(teacher), _ptr(center), c_float(student_temp), c_float(teacher_temp),
+                                                _ptr(loss_rows), _ptr(dstudent), _ptr(colsum), c_int(B), c_int(V), c_int(P), _stream())
+        _chk(rc, "chadavit_dino_loss_multicrop")
+        return loss_rows, dstudent, colsum
     if isinstance(teacher_temp, torch.Tensor):
         _req(teacher_temp, F32, "teacher_temp")
         rc = lib().chadavit_dino_loss_dev(_ptr(student), _ptr(teacher), _ptr(center), c_float(student_temp), _ptr(teacher_temp),

@@ -212,6 +212,12 @@ int chadavit_weightnorm_bwd_g(const float* dw, const float* v, const float* g, c
 int chadavit_dino_loss(const float* student, const float* teacher, const float* center, float student_temp,
                        float teacher_temp, float* loss_rows, chada_bf16* dstudent, float* teacher_colsum, int B,
                        int P, void* stream);
+/* The same loss over V >= 2 student views, student [V*B, P] view-major (losses/dino.py:69-100 with `student_out.chunk(V)`: teacher view
+ * iq < 2 against every student view v != iq, 2V - 2 terms): the STANDARD-DINO multi-crop form.  The reference's DINO.training_step never
+ * feeds the local crops to its loss (src/methods/dino.py:300-325, base.py:566-620) -- this serves the separately flagged option
+ * `method_kwargs.standard_multicrop_loss`, not the parity path.  dstudent bf16 [V*B, P] (may be NULL). */
+int chadavit_dino_loss_multicrop(const float* student, const float* teacher, const float* center, float student_temp, float teacher_temp,
+                                 float* loss_rows, chada_bf16* dstudent, float* teacher_colsum, int B, int V, int P, void* stream);
 int chadavit_center_ema(float* center, const float* colsum, float inv_count, float momentum, int P, void* stream);
 
 /* ---------------------------------------------------------------------------------------------

@@ -278,8 +278,10 @@ def teacher_temp_schedule(warmup_temp: float, temp: float, warmup_epochs: int, n
 
 
 def dino_loss(student: torch.Tensor, teacher: torch.Tensor, center: torch.Tensor, teacher_temp: float,
-              student_temp: float = 0.1) -> torch.Tensor:
-    s = (student / student_temp).chunk(2)
+              student_temp: float = 0.1, n_student_views: int = 2) -> torch.Tensor:
+    """losses/dino.py:69-100.  `n_student_views` is the reference's `self.num_large_crops` (:82): 2 in the reference's DINO; the number
+    of crops for the standard-DINO multi-crop loss (the build's flagged option: local crops as extra student views)."""
+    s = (student / student_temp).chunk(n_student_views)
     q = F.softmax((teacher - center) / teacher_temp, dim=-1).detach().chunk(2)
     total = 0.0
     n = 0
@@ -331,7 +333,7 @@ def split_prefix(sd: Params, prefix: str) -> Params:
 
 def training_step(sd: Params, crops: List[torch.Tensor], num_channels: List[List[int]], num_large_crops: int,
                   teacher_temp: float, student_temp: float = 0.1, nheads: int = 2, padded: bool = False,
-                  freeze_last_layer: bool = True, clip_grad: float = 0.0, norm_last_layer: bool = True):
+                  freeze_last_layer: bool = True, clip_grad: float = 0.0, norm_last_layer: bool = True, standard_multicrop: bool = False):
     """Student fwd on global crops (-> z) and on local crops (backbone only, result unused: DINO does
     not override multicrop_forward, base.py:566-620); teacher fwd on global crops; loss over the 2x2
     cross pairs; backward.  Returns (loss, grads{name: tensor|None}, new_center, aux).
@@ -354,15 +356,23 @@ def training_step(sd: Params, crops: List[torch.Tensor], num_channels: List[List
         f = fwd(bb, crops[k], num_channels[k], nheads)
         feats.append(f)
         z.append(head_forward(hd, f, hbn))
+    if standard_multicrop:
+        # NOT the reference's default: the standard-DINO multi-crop loss (the reference's own DINOLoss arithmetic with num_large_crops =
+        # number of crops, and a multicrop_forward that adds the head's output) -- local crops with gradient, through the head, into the loss
+        for k in range(num_large_crops, len(crops)):
+            f = fwd(bb, crops[k], num_channels[k], nheads)
+            feats.append(f)
+            z.append(head_forward(hd, f, hbn))
     with torch.no_grad():
         for k in range(num_large_crops, len(crops)):  # local crops: forward only, no loss
-            feats.append(fwd(bb, crops[k], num_channels[k], nheads))
+            if not standard_multicrop:
+                feats.append(fwd(bb, crops[k], num_channels[k], nheads))
         tfeats = [fwd(tbb, crops[k], num_channels[k], nheads) for k in range(num_large_crops)]
         tz = [head_forward(thd, f, tbn) for f in tfeats]
     p_s = torch.cat(z)
     p_t = torch.cat(tz)
     center = sd["dino_loss_func.center"]
-    loss = dino_loss(p_s, p_t, center, teacher_temp, student_temp)
+    loss = dino_loss(p_s, p_t, center, teacher_temp, student_temp, n_student_views=len(z))
     loss.backward()
     grads: Dict[str, Optional[torch.Tensor]] = {}
     for k, v in bb.items():

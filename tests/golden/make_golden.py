@@ -106,11 +106,24 @@ def build_sd(D, PR, seeds=(1, 2, 3, 4, 5), hidden=2048, bott=256, use_bn=False):
 
 
 def golden_step(name, D, PR, nch, sizes, n_large, epoch, clip_grad=0.0, lr=5e-4, wd=1e-4, base_tau=0.9995,
-                max_steps=100, use_bn=False, norm_last_layer=True):
+                max_steps=100, use_bn=False, norm_last_layer=True, standard_multicrop=False):
     cfg = refshim.dino_cfg(embed_dim=D, num_prototypes=PR, num_large_crops=n_large,
                            num_small_crops=len(sizes) - n_large, clip_grad=clip_grad, lr=lr, weight_decay=wd,
                            base_tau=base_tau, use_bn_in_head=use_bn, norm_last_layer=norm_last_layer)
-    model = ref.DINO(cfg)
+    if standard_multicrop:
+        # NOT the reference's default behaviour.  The standard-DINO multi-crop loss assembled from the reference's own pieces: a subclass
+        # whose multicrop_forward (base.py:566-620) also returns the head's output for the local crops -- BaseMethod.training_step then
+        # appends it to outs["z"] (base.py:700-706) and DINO.training_step concatenates all of it (dino.py:311) -- and the reference's
+        # DINOLoss chunking the student logits into num_crops views (losses/dino.py:82 with num_large_crops = num_crops).
+        class StandardMultiCropDINO(ref.DINO):
+            def multicrop_forward(self, X, index):
+                out = super().multicrop_forward(X, index)
+                out["z"] = self.head(out["feats"])
+                return out
+        model = StandardMultiCropDINO(cfg)
+        model.dino_loss_func.num_large_crops = len(sizes)
+    else:
+        model = ref.DINO(cfg)
     sd = build_sd(D, PR, use_bn=use_bn)
     model.load_state_dict(sd)
     imgs = P.make_images(nch, sizes, seed=7)
@@ -130,7 +143,8 @@ def golden_step(name, D, PR, nch, sizes, n_large, epoch, clip_grad=0.0, lr=5e-4,
     loss = model.training_step(batch, 0)
     for h in hooks:
         h.remove()
-    assert len(seen["backbone"]) == len(sizes) and len(seen["momentum_backbone"]) == len(seen["head"]) == len(seen["momentum_head"]) == n_large
+    assert len(seen["backbone"]) == len(sizes) and len(seen["momentum_backbone"]) == len(seen["momentum_head"]) == n_large
+    assert len(seen["head"]) == (len(sizes) if standard_multicrop else n_large)
     loss.backward()
     model.on_after_backward()
     names, gnorms, none_names, gsub = [], [], [], []
@@ -150,7 +164,7 @@ def golden_step(name, D, PR, nch, sizes, n_large, epoch, clip_grad=0.0, lr=5e-4,
            "none_grad_names": np.asarray(none_names),
            "center_new": f32(model.dino_loss_func.center)[0, :256],
            "center_new_sum": np.float64(model.dino_loss_func.center.double().sum().item()), "use_bn": int(use_bn),
-           "norm_last_layer": int(norm_last_layer)}
+           "norm_last_layer": int(norm_last_layer), "standard_multicrop": int(standard_multicrop)}
     # a fixed spread of <= 1024 elements of EVERY gradient tensor of the reference (grad_subset_index), in the order of grad_names
     out["gsub_vals"] = np.concatenate(gsub)
     out["gsub_counts"] = np.asarray([len(v) for v in gsub])
@@ -517,6 +531,10 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "lars":
         golden_lars("lars")
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "standard_multicrop":
+        # round 4: the standard-DINO multi-crop loss (flagged option, NOT the reference's default): 2 global + 3 local crops, mixed channels
+        golden_step("step_tiny_standard_multicrop", 192, 4096, [3, 1, 5, 2], [224, 224, 96, 96, 96], 2, 1, standard_multicrop=True)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "steps_all":
         # round 4: every step golden again (same arguments as below), now also holding the passes' outputs and a spread of every gradient

@@ -71,8 +71,9 @@ def step_outputs_vs_golden(outs, g, copies=1, cos_min=0.999, rel_max=2e-2, what=
 
     rpc = [int(v) for v in g["outs::feats_rows_per_crop"]]
     nl = int(g["n_large"])
+    zr = rpc if int(g["outs::z_shape"][0]) == sum(rpc) else rpc[:nl]   # (standard multi-crop option: every crop has student logits)
     got = {"feats": stack(torch.cat([f.detach().float().cpu() for f in outs["feats"]]), rpc),
-           "z": stack(outs["z"], rpc[:nl]), "momentum_z": stack(outs["momentum_z"], rpc[:nl])}
+           "z": stack(outs["z"], zr), "momentum_z": stack(outs["momentum_z"], rpc[:nl])}
     if outs.get("momentum_feats") is not None:
         got["momentum_feats"] = stack(outs["momentum_feats"], rpc[:nl])
     worst = (1.0, 0.0, None)
@@ -106,8 +107,9 @@ def step_outputs_vs_oracle(outs, aux, copies=1, cos_min=0.999, rel_max=2e-2, log
     """The same four outputs against the CPU oracle's `aux` (oracle/chada_ref.py::training_step), on ALL columns (the golden holds the
     first 256 prototypes of the logits); `aux` is pinned to the reference by tests/test_oracle_golden.py."""
     import torch
+    nz = aux["student_logits"].shape[0] // aux["teacher_feats"][0].shape[0]    # student views (2, or all crops with the standard option)
     refs = {"feats": list(aux["feats"]), "momentum_feats": list(aux["teacher_feats"]),
-            "z": list(aux["student_logits"].chunk(len(aux["teacher_feats"]))), "momentum_z": list(aux["teacher_logits"].chunk(len(aux["teacher_feats"])))}
+            "z": list(aux["student_logits"].chunk(nz)), "momentum_z": list(aux["teacher_logits"].chunk(len(aux["teacher_feats"])))}
     worst = (1.0, 0.0, None)
     feat_bar = (cos_min, rel_max)
     for key, per_crop in refs.items():

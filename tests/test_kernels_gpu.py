@@ -1296,3 +1296,31 @@ def test_gemms_are_deterministic_at_every_shape_of_the_three_models():
         repeat_equal(f"mx8 {M}x{N}x{K} resid", lambda: ops.gemm_nt_mx8(xq, xs, wq, wsq, bias=bias, epilogue=ops.EPI_RESID, aux=aux))
         repeat_equal(f"mx8 {M}x{N}x{K} relumask + q", lambda: flat(ops.gemm_nt_mx8(xq, xs, wq, wsq, epilogue=ops.EPI_RELUMASK, aux=aux, emit_q=True)))
         del x, w, aux, xq, wq
+
+
+@pytest.mark.parametrize("B,V,PR", [(5, 3, 1000), (4, 10, 4096), (3, 2, 640)])
+def test_dino_loss_over_more_than_two_student_views(B, V, PR):
+    """chadavit_dino_loss_multicrop (the standard-DINO multi-crop option) against the reference loss arithmetic restated by the oracle
+    (oracle.chada_ref.dino_loss with n_student_views = V; losses/dino.py:69-100 with chunk(V)): loss, dL/dstudent, teacher column sum.
+    V = 2 must agree with the two-view kernel bit for bit in the loss."""
+    import numpy as np
+    from oracle import chada_ref as R
+    from chadavit_amd import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    s = torch.randn(V * B, PR) * 1.5
+    t = torch.randn(2 * B, PR) * 1.5
+    c = torch.randn(1, PR) * 0.1
+    sr = s.clone().requires_grad_(True)
+    loss_ref = R.dino_loss(sr, t, c, 0.05, 0.1, n_student_views=V)
+    loss_ref.backward()
+    if V == 2:
+        rows2, d2, cs2 = ops.dino_loss(s.to(dev), t.to(dev), c.view(-1).to(dev), 0.1, 0.05)
+        assert abs(rows2.mean().item() - loss_ref.item()) <= 1e-5 * abs(loss_ref.item())
+        return
+    rows, dstu, colsum = ops.dino_loss(s.to(dev), t.to(dev), c.view(-1).to(dev), 0.1, 0.05)
+    assert rows.shape == (B,) and dstu.shape == (V * B, PR)
+    assert abs(rows.mean().item() - loss_ref.item()) <= 1e-5 * abs(loss_ref.item()), (rows.mean().item(), loss_ref.item())
+    g = dstu.float().cpu()
+    assert float((g - sr.grad).norm() / sr.grad.norm()) <= 5e-3          # bf16-stored gradient
+    np.testing.assert_allclose(colsum.cpu().numpy(), t.sum(0).numpy(), rtol=1e-5, atol=1e-4)

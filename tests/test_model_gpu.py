@@ -560,6 +560,71 @@ def test_training_step_with_trained_prototype_norms_vs_golden_and_oracle(name):
     assert (moved > 0) == (epoch >= 1), moved
 
 
+def test_training_step_with_the_standard_multicrop_loss_vs_golden_and_oracle():
+    """`method_kwargs.standard_multicrop_loss = True` -- a BUILD-SIDE option, off by default and NOT the reference's behaviour (its DINO
+    computes the local crops' features and drops them): the DINO paper's multi-crop loss, local crops through the head and into the loss as
+    extra student views (2 teacher x 5 student views here), trained through.  Golden: a subclass of the reference's DINO whose
+    multicrop_forward also returns the head's output, with the reference's DINOLoss chunking the student logits into all crops
+    (tests/golden/make_golden.py `standard_multicrop`).  Loss, every pass's outputs (local crops' logits included), gradients (two
+    backward passes per network accumulate), the centre; and the parity path must be untouched by the flag being off."""
+    from chadavit_amd import ops
+    from chadavit_amd.data.channels_strategies import one_channel_collate_fn
+    from chadavit_amd.methods.dino import DINO
+    from chadavit_amd.trainer import Trainer
+    from tests.golden_util import grad_subsets_vs_golden, step_outputs_vs_golden, step_outputs_vs_oracle
+    dev = _dev()
+    g = np.load(os.path.join(GOLDEN, "step_tiny_standard_multicrop.npz"))
+    D, PR, n_large, epoch = int(g["D"]), int(g["P"]), int(g["n_large"]), int(g["epoch"])
+    nch, sizes = [int(c) for c in g["nch"]], [int(s) for s in g["sizes"]]
+    sd = build_sd(D, PR)
+    crops, labels, ncl = one_channel_collate_fn(P.make_images(nch, sizes, seed=7))
+    loss_o, grads_o, newc_o, aux = R.training_step(sd, crops, ncl, n_large, float(g["teacher_temp"]), freeze_last_layer=False, standard_multicrop=True)
+    for fused_min_rows in (None, 0):   # GEMM + LayerNorm chain, and the whole-block kernels forced
+        cfg = _cfg(D, PR, n_large, len(sizes) - n_large, lr=float(g["lr"]), wd=float(g["wd"]), base_tau=float(g["base_tau"]))
+        cfg.method_kwargs.standard_multicrop_loss = True
+        model = DINO(cfg)
+        assert model.standard_multicrop_loss and model.dino_loss_func.num_large_crops == len(sizes)
+        model.load_state_dict(sd)
+        model = model.to(dev)
+        if fused_min_rows is not None:
+            model.backbone.fused_min_rows = model.momentum_backbone.fused_min_rows = fused_min_rows
+        tr = Trainer(max_epochs=10, steps_per_epoch=10)
+        tr.current_epoch = epoch
+        tr.attach(model)
+        model.current_epoch = epoch
+        model.on_train_epoch_start()
+        with ops.LaunchProfiler() as prof:
+            loss = model.training_step(([c.to(dev) for c in crops], labels.to(dev), ncl), 1)
+            loss.backward()
+            model.on_after_backward()
+        summ = prof.summary()   # both backbone passes of the student ran with saves (the local one too): two sets of backward launches
+        assert sum(v["launches"] for k, v in summ.items() if k[0] == "attn_bwd") >= 2 * 11
+        assert abs(loss.item() - float(g["loss"])) <= 2e-2, (loss.item(), float(g["loss"]))
+        torch.cuda.synchronize()
+        assert model._last_outs["z"].shape[0] == len(sizes) * len(nch)
+        print("standard multicrop, outputs vs reference-subclass golden:", step_outputs_vs_golden(model._last_outs, g))
+        print("standard multicrop, outputs vs oracle:", step_outputs_vs_oracle(model._last_outs, aux))
+        named = dict(model.named_parameters())
+        print("standard multicrop, gradient spread:", grad_subsets_vs_golden(named, g))
+        tot_h = tot_r = 0.0
+        worst = (1.0, None)
+        for n, gn in zip(g["grad_names"], g["grad_norms"]):
+            gh = named[str(n)].grad
+            assert gh is not None, str(n)
+            tot_h += gh.double().norm().item() ** 2
+            tot_r += float(gn) ** 2
+            go = grads_o[str(n)]
+            if float(gn) > 1e-4 * np.sqrt(go.numel()) * 1e-2:
+                worst = min(worst, (_cos(gh, go), str(n)))
+        assert abs(np.sqrt(tot_h) - np.sqrt(tot_r)) <= 5e-2 * np.sqrt(tot_r), (np.sqrt(tot_h), np.sqrt(tot_r))
+        assert worst[0] >= 0.99, worst
+        for n in (str(n) for n in g["none_grad_names"]):
+            assert named[n].grad is None, n
+        np.testing.assert_allclose(model.dino_loss_func.center[0, :256].float().cpu().numpy(), g["center_new"], atol=2e-3)
+        tr.optimizer.step()   # and the step goes through the optimiser
+        assert all(torch.isfinite(p_).all() for p_ in model.parameters())
+
+
 def test_training_step_is_deterministic_under_allocator_churn():
     """The same training step (golden step_tiny_fused_rows: whole-block kernels on the global passes, GEMM chain on the local one)
     three times in one process, the caching allocator's free blocks refilled with large values and with NaN in between: loss and

@@ -120,7 +120,9 @@ def test_validation_step_matches_reference():
 
 
 _STEP_GOLDENS = ["step_tiny_multicrop", "step_tiny_c1_clip", "step_small_mixed", "step_base_c10", "step_tiny_bn_head",
-                 "step_tiny_trained_prototype_norms", "step_tiny_trained_prototype_norms_epoch0"]
+                 "step_tiny_trained_prototype_norms", "step_tiny_trained_prototype_norms_epoch0",
+                 # the standard-DINO multi-crop loss (flagged option; golden from a subclass of the reference's DINO, make_golden.py)
+                 "step_tiny_standard_multicrop"]
 if os.environ.get("CHADAVIT_SLOW_TESTS"):  # 26282-row Tiny step: 85 s of oracle on 8 cores (checked when the golden was made)
     _STEP_GOLDENS.append("step_tiny_fused_rows")
 
@@ -131,7 +133,8 @@ def test_training_step_matches_reference(name):
     sd, crops, ncl = _step_case(g)
     loss, grads, newc, aux = R.training_step(sd, crops, ncl, int(g["n_large"]), float(g["teacher_temp"]),
                                              freeze_last_layer=int(g["epoch"]) < 1, clip_grad=float(g["clip_grad"]),
-                                             norm_last_layer=bool(int(g["norm_last_layer"])) if "norm_last_layer" in g.files else True)
+                                             norm_last_layer=bool(int(g["norm_last_layer"])) if "norm_last_layer" in g.files else True,
+                                             standard_multicrop=bool(int(g["standard_multicrop"])) if "standard_multicrop" in g.files else False)
     assert abs(loss.item() - float(g["loss"])) < 2e-6 * abs(float(g["loss"]))
     none_names = set(str(n) for n in g["none_grad_names"])
     for n, gn in zip(g["grad_names"], g["grad_norms"]):
