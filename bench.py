@@ -45,6 +45,11 @@ WORKLOADS = {
     # the north star's wording of the target ("Tiny/16 ... 1-10-channel multi-crop batches"): configs[1] with the channel mix of configs[2]
     "cfg2-mixed": dict(desc="ChAda-ViT-Tiny/16, variable 1-10 channel, DINO 2 global + 8 local crops", D=192, channels="1-10",
                        n_global=2, n_local=8, P=4096, batch=256),
+    # NOT a BASELINE config and not the reference's behaviour: the DINO paper's multi-crop loss (method_kwargs.standard_multicrop_loss, a
+    # build-side option) -- the local crops go through the head, reach the loss and are trained through (SURVEY 8(d) "standard-DINO" column)
+    "cfg2-standard": dict(desc="ChAda-ViT-Tiny/16, fixed 3-channel 224x224, 2 global + 8 local crops, STANDARD-DINO multi-crop loss (local "
+                               "crops in the loss, with backward; flagged option, not the reference's semantics)", D=192, channels="3",
+                          n_global=2, n_local=8, P=4096, batch=512, standard=True),
     "cfg1": dict(desc="ChAda-ViT-Tiny/16, 1-channel 224x224, DINO 2 global crops only", D=192, channels="1", n_global=2,
                  n_local=0, P=4096, batch=4),
     "cfg3": dict(desc="ChAda-ViT-Small/16, variable 1-10 channel, DINO 2 global + 8 local crops", D=384, channels="1-10",
@@ -101,13 +106,15 @@ def f_head(D, P, hidden=2048, bott=256):
     return 2 * (D * hidden + hidden * hidden + hidden * bott + bott * P)
 
 
-def gflop_per_image(channels, D, P, n_global, n_local, cls_last=False):
-    """mean over the channel distribution of: 2*3*F_fwd(224) + 2*F_fwd(224) + n_local*F_bb(96) (parity semantics).
+def gflop_per_image(channels, D, P, n_global, n_local, cls_last=False, standard=False):
+    """mean over the channel distribution of: 2*3*F_fwd(224) + 2*F_fwd(224) + n_local*F_bb(96) (parity semantics); with `standard` (the
+    standard-DINO multi-crop option) the local crops cost n_local*3*F_fwd(96) instead: head included, forward + backward.
     cls_last=False: the reference's algorithm (every row through every block); True: what this build executes."""
     tot = 0.0
     for C in channels:
         ffwd = f_backbone(C, 224, D, cls_last=cls_last) + f_head(D, P)
-        tot += n_global * 3 * ffwd + n_global * ffwd + n_local * f_backbone(C, 96, D, cls_last=cls_last)
+        local = 3 * (f_backbone(C, 96, D, cls_last=cls_last) + f_head(D, P)) if standard else f_backbone(C, 96, D, cls_last=cls_last)
+        tot += n_global * 3 * ffwd + n_global * ffwd + n_local * local
     return tot / len(channels) / 1e9
 
 
@@ -134,7 +141,7 @@ def make_cfg(wl):
         "scheduler": {"name": "warmup_cosine"},
         "momentum": {"base_tau": 0.9995, "final_tau": 1.0},
         "method_kwargs": {"proj_hidden_dim": 2048, "proj_output_dim": 256, "num_prototypes": wl["P"],
-                          "warmup_teacher_temperature_epochs": 30},
+                          "warmup_teacher_temperature_epochs": 30, "standard_multicrop_loss": bool(wl.get("standard", False))},
     })
 
 
@@ -639,8 +646,11 @@ def other_workload_leg(name, args, dev, steps=3, warmup=2, graph=False, batch=No
            "dtype": "fp8-weights (MX e4m3 x e4m3 forward GEMMs and the FFN's two dX GEMMs; bf16 elsewhere)" if wl.get("weight_dtype") == "fp8" else "bf16",
            "launch": "one hipGraph per step (GraphedTrainStep)" if graph else "eager"}
     chans = list(range(1, 11)) if "-" in wl["channels"] else [int(wl["channels"])]
-    gf_exec = gflop_per_image(chans, wl["D"], wl["P"], wl["n_global"], wl["n_local"], cls_last=bool(model.backbone.cls_only_last_block))
+    gf_exec = gflop_per_image(chans, wl["D"], wl["P"], wl["n_global"], wl["n_local"], cls_last=bool(model.backbone.cls_only_last_block),
+                              standard=bool(wl.get("standard", False)))
     res["executed_gflop_per_image"] = round(gf_exec, 1)
+    if wl.get("standard"):
+        res["algorithmic_gflop_per_image"] = round(gflop_per_image(chans, wl["D"], wl["P"], wl["n_global"], wl["n_local"], standard=True), 1)
     res["mfma_fraction_whole_step"] = round(res["images_per_s"] * gf_exec / 1e3 / PEAK_BF16_TFLOPS, 4)
     if not args.no_launch_profile and not graph:
         summ = launch_profile(tr, batch, warmup + steps, nch, wl, dev, 0, in_step_steps=1)
@@ -871,11 +881,12 @@ def main():
         ms = 1e3 * dt / args.steps
         value = B * world * args.steps / dt
         chans = sorted(set(nch)) if "-" not in wl["channels"] else list(range(1, 11))
-        gf_img = gflop_per_image(chans if "-" in wl["channels"] else [int(wl["channels"])], wl["D"], wl["P"], wl["n_global"], wl["n_local"])
+        gf_img = gflop_per_image(chans if "-" in wl["channels"] else [int(wl["channels"])], wl["D"], wl["P"], wl["n_global"], wl["n_local"],
+                                 standard=bool(wl.get("standard", False)))
         # utilisation is priced with the FLOPs the build EXECUTES: with return_all_tokens = False its last block runs on the CLS rows
         # only (same outputs and gradients as the reference's full-width block)
         gf_exec = gflop_per_image(chans if "-" in wl["channels"] else [int(wl["channels"])], wl["D"], wl["P"], wl["n_global"], wl["n_local"],
-                                  cls_last=bool(model.backbone.cls_only_last_block))
+                                  cls_last=bool(model.backbone.cls_only_last_block), standard=bool(wl.get("standard", False)))
         step_tflops = value * gf_exec / 1e3 / world
         out = {
             "metric": "images/sec ChAda-ViT DINO multi-crop pretrain (whole training step)",
@@ -941,9 +952,9 @@ def main():
             # ("cfg2-1024": the headline workload at twice the images per GPU -- the per-step constants (optimiser, EMA, weight casts and
             # packings, the heads) amortise further; informational, the headline stays at 512 per GPU for round-over-round comparisons)
             for name, kw in (("cfg3", {}), ("cfg5", {}), ("cfg1", {"steps": 30, "warmup": 3}), ("cfg1-graph", {"steps": 30, "warmup": 3, "graph": True}),
-                             ("cfg2-1024", {"steps": 4, "warmup": 2, "batch": 1024})):
+                             ("cfg2-1024", {"steps": 4, "warmup": 2, "batch": 1024}), ("cfg2-standard", {"steps": 4, "warmup": 2, "wl_name": "cfg2-standard"})):
                 try:
-                    legs[name] = other_workload_leg(name.split("-")[0], args, dev, **kw)
+                    legs[name] = other_workload_leg(kw.pop("wl_name", name.split("-")[0]), args, dev, **kw)
                 except Exception as e:  # noqa: BLE001 - the headline number must still be reported
                     legs[name] = {"error": repr(e)}
             out["config"]["other_workloads"] = legs

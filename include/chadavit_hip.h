@@ -157,8 +157,9 @@ int chadavit_attn_bwd_parts(const chada_bf16* qkv, const chada_bf16* out, const 
                             int D, int H, int parts, void* stream);
 /* The backward for dh 96 / 192 on v_mfma_f32_32x32x16_bf16 (csrc/attention_bwd_m32.hip; autograd of chada_vit.py:105-111): a wave owns
  * 32 query rows (dQ) or 32 key rows (dK/dV), the saved LSE is the softmax's exponent reference, -delta rides in the dP MFMAs' C operand.
- * `parts` as above (a lone delta request, parts & 3 == 1, returns 3); `scale` = the model's softmax scale.  chadavit_attn_bwd[_parts]
- * dispatch here for these head widths. */
+ * `parts` as above (a lone delta request, parts & 3 == 1, returns 3); `scale` = the model's softmax scale.  Built and measured in
+ * round 4: correct, and 3 % (dQ) / 14 % (dK/dV) slower than the 16x16x32 pair at the bench's shapes (profiles/r04b_attention_bwd_m32.md),
+ * so chadavit_attn_bwd[_parts] dispatch here only with CHADAVIT_ATTN_BWD_M32=1 (A/B runs). */
 int chadavit_attn_bwd_m32(const chada_bf16* qkv, const chada_bf16* out, const chada_bf16* dout, const float* lse, chada_bf16* dqkv,
                           float* delta, const int* cu_seqlens, const int* work, int n_work, int T, int D, int H, int parts, float scale,
                           void* stream);
