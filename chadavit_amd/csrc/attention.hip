@@ -1538,13 +1538,11 @@ extern "C" int chadavit_attn_fwd(const chada_bf16* qkv_, chada_bf16* out_, float
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const float scale = 1.0f / sqrtf((float)dh);
   const dim3 blk(256);
-  static const bool use_dma = getenv("CHADAVIT_ATTN_NO_DMA") == nullptr;
+  // (round 4: the CHADAVIT_ATTN_NO_DMA fallbacks -- register-staged instances of every LDS-DMA kernel -- are gone; the register-staged
+  // kernels remain for the head widths that have no DMA instance: 128 / 256 forward, 32 / 64 / 128 / 256 backward)
 #define FWD_DMA_CASE(DHV, CBV)                                                                                     \
   case DHV:                                                                                                       \
-    if (use_dma)                                                                                                  \
-      hipLaunchKernelGGL((attn_fwd_dma_kernel<DHV, CBV>), dim3(n_work * (2 / CBV) * H), blk, 0, s, qkv, out, lse, cu_seqlens, work, T, D, H, scale); \
-    else                                                                                                          \
-      hipLaunchKernelGGL((attn_fwd_kernel<DHV, CBV>), dim3(n_work * (2 / CBV) * H), blk, 0, s, qkv, out, lse, cu_seqlens, work, T, D, H, scale); \
+    hipLaunchKernelGGL((attn_fwd_dma_kernel<DHV, CBV>), dim3(n_work * (2 / CBV) * H), blk, 0, s, qkv, out, lse, cu_seqlens, work, T, D, H, scale); \
     break;
 #define FWD_CASE(DHV, CBV)                                                                                         \
   case DHV:                                                                                                       \
@@ -1557,10 +1555,7 @@ extern "C" int chadavit_attn_fwd(const chada_bf16* qkv_, chada_bf16* out_, float
     FWD_DMA_CASE(32, 2) FWD_DMA_CASE(64, 2) FWD_DMA_CASE(96, 2) FWD_DMA_CASE(192, 2)
     FWD_CASE(128, 2) FWD_CASE(256, 1)   // embed_dim 256 / 512 with the factory's two heads: the register-staged kernels (cold path)
     case 384:  // eight waves x 16 query rows per 128-row tile (FwdDmaCfg<384>::NW)
-      if (use_dma)
-        hipLaunchKernelGGL((attn_fwd_dma_kernel<384, 1>), dim3(n_work * H), dim3(512), 0, s, qkv, out, lse, cu_seqlens, work, T, D, H, scale);
-      else
-        hipLaunchKernelGGL((attn_fwd_kernel<384, 1>), dim3(n_work * 2 * H), blk, 0, s, qkv, out, lse, cu_seqlens, work, T, D, H, scale);
+      hipLaunchKernelGGL((attn_fwd_dma_kernel<384, 1>), dim3(n_work * H), dim3(512), 0, s, qkv, out, lse, cu_seqlens, work, T, D, H, scale);
       break;
     default: return 2;
   }
@@ -1586,7 +1581,6 @@ static int attn_bwd_launch(const chada_bf16* qkv_, const chada_bf16* out_, const
   bf16_t* dqkv = reinterpret_cast<bf16_t*>(dqkv_);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dh != 32 && dh != 64 && dh != 96 && dh != 128 && dh != 192 && dh != 256 && dh != 384) return 2;
-  static const bool use_dma = getenv("CHADAVIT_ATTN_NO_DMA") == nullptr;
   const bool fuse_delta = (parts & 3) == 3;  // delta comes out of the dQ kernel; the stand-alone pass only if dQ is not run here
   if ((parts & 1) && !fuse_delta) {
     int dgrid = (T + 3) / 4;
@@ -1603,30 +1597,46 @@ static int attn_bwd_launch(const chada_bf16* qkv_, const chada_bf16* out_, const
     return rest ? chadavit_attn_bwd_m32(qkv_, out_, dout_, lse, dqkv_, delta, cu_seqlens, work, n_work, T, D, H, rest, scale, stream) : 0;
   }
   const dim3 blk(256);
-#define BWD_CASE(DHV, CBV)                                                                                         \
+#define BWD_REG_CASE(DHV, CBV) /* register-staged kernels: head widths without an LDS-DMA instance */                      \
   case DHV:                                                                                                       \
-    if ((parts & 2) && fuse_delta && use_dma && DHV == 96)                                                        \
-      hipLaunchKernelGGL((attn_bwd_dq_dma_kernel<96, 2, true>), dim3(n_work * H), blk, 0, s, qkv, dout, lse, delta, dqkv, cu_seqlens, work, T, D, H, scale, out); \
-    else if ((parts & 2) && fuse_delta && use_dma && DHV == 192) /* one query block per wave: with two, Q + dO + dQ spill (65-124 VGPRs) */ \
-      hipLaunchKernelGGL((attn_bwd_dq_dma_kernel<(DHV == 192 ? 192 : 96), 1, true>), dim3(n_work * 2 * H), blk, 0, s, qkv, dout, lse, delta, dqkv, cu_seqlens, work, T, D, H, scale, out); \
-    else if ((parts & 2) && fuse_delta && use_dma && DHV == 384) /* eight waves x 16 query rows, fragment-major K / V / K^T stages */ \
-      hipLaunchKernelGGL((attn_bwd_dq_fm_kernel<384, 1>), dim3(n_work * H), dim3(512), 0, s, qkv, dout, lse, delta, dqkv, cu_seqlens, work, T, D, H, scale, out); \
-    else if ((parts & 2) && fuse_delta)                                                                           \
+    if ((parts & 2) && fuse_delta)                                                                                \
       hipLaunchKernelGGL((attn_bwd_dq_kernel<DHV, CBV, true>), dim3(n_work * (2 / CBV) * H), blk, 0, s, qkv, dout, lse, delta, dqkv, cu_seqlens, work, T, D, H, scale, out); \
     else if (parts & 2)                                                                                           \
       hipLaunchKernelGGL((attn_bwd_dq_kernel<DHV, CBV, false>), dim3(n_work * (2 / CBV) * H), blk, 0, s, qkv, dout, lse, delta, dqkv, cu_seqlens, work, T, D, H, scale, out); \
-    if ((parts & 4) && use_dma && DHV == 384) /* one wave per SIMD (288 registers of K / V / dK / dV state), 49 KiB row-major stages */ \
-      hipLaunchKernelGGL((attn_bwd_dkv_dma_kernel<(DHV == 384 ? 384 : 96), (DHV == 384 ? 1 : 2)>), dim3((DHV == 384 ? 2 : 1) * n_work * H), blk, 0, s, qkv, dout, lse, delta, dqkv, cu_seqlens, work, T, D, H, scale); \
-    else if ((parts & 4) && use_dma && (DHV == 96 || DHV == 192))                                                 \
-      hipLaunchKernelGGL((attn_bwd_dkv_dma_kernel<(DHV == 192 ? 192 : 96), (DHV == 192 ? 1 : 2)>), dim3((DHV == 192 ? 2 : 1) * n_work * H), blk, 0, s, qkv, dout, lse, delta, dqkv, cu_seqlens, work, T, D, H, scale); \
-    else if (parts & 4)                                                                                           \
+    if (parts & 4)                                                                                                \
       hipLaunchKernelGGL((attn_bwd_dkv_kernel<DHV, (DHV <= 96 ? 2 : 1)>), dim3((DHV <= 96 ? 1 : 2) * n_work * H), blk, 0, s, qkv, dout, lse, delta, dqkv, cu_seqlens, work, T, D, H, scale); \
     break;
+  // LDS-DMA kernels (dh 96 / 192 / 384).  With the delta bit the dQ kernel produces delta itself; a dQ request WITHOUT it (the host's
+  // two-stream form: delta first, then dQ and dK/dV side by side) reads the caller's.
   switch (dh) {
-    BWD_CASE(32, 2) BWD_CASE(64, 2) BWD_CASE(96, 2) BWD_CASE(192, 2) BWD_CASE(384, 1) BWD_CASE(128, 2) BWD_CASE(256, 1)
+    BWD_REG_CASE(32, 2) BWD_REG_CASE(64, 2) BWD_REG_CASE(128, 2) BWD_REG_CASE(256, 1)
+    case 96:
+      if ((parts & 2) && fuse_delta)
+        hipLaunchKernelGGL((attn_bwd_dq_dma_kernel<96, 2, true>), dim3(n_work * H), blk, 0, s, qkv, dout, lse, delta, dqkv, cu_seqlens, work, T, D, H, scale, out);
+      else if (parts & 2)
+        hipLaunchKernelGGL((attn_bwd_dq_dma_kernel<96, 2, false>), dim3(n_work * H), blk, 0, s, qkv, dout, lse, delta, dqkv, cu_seqlens, work, T, D, H, scale, out);
+      if (parts & 4)
+        hipLaunchKernelGGL((attn_bwd_dkv_dma_kernel<96, 2>), dim3(n_work * H), blk, 0, s, qkv, dout, lse, delta, dqkv, cu_seqlens, work, T, D, H, scale);
+      break;
+    case 192:  // one query block per wave in dQ: with two, Q + dO + dQ spill (65-124 VGPRs)
+      if ((parts & 2) && fuse_delta)
+        hipLaunchKernelGGL((attn_bwd_dq_dma_kernel<192, 1, true>), dim3(n_work * 2 * H), blk, 0, s, qkv, dout, lse, delta, dqkv, cu_seqlens, work, T, D, H, scale, out);
+      else if (parts & 2)
+        hipLaunchKernelGGL((attn_bwd_dq_dma_kernel<192, 1, false>), dim3(n_work * 2 * H), blk, 0, s, qkv, dout, lse, delta, dqkv, cu_seqlens, work, T, D, H, scale, out);
+      if (parts & 4)
+        hipLaunchKernelGGL((attn_bwd_dkv_dma_kernel<192, 1>), dim3(2 * n_work * H), blk, 0, s, qkv, dout, lse, delta, dqkv, cu_seqlens, work, T, D, H, scale);
+      break;
+    case 384:  // dQ: eight waves x 16 query rows, fragment-major K / V / K^T stages; dK/dV: one wave per SIMD (288 registers of state)
+      if ((parts & 2) && fuse_delta)
+        hipLaunchKernelGGL((attn_bwd_dq_fm_kernel<384, 1>), dim3(n_work * H), dim3(512), 0, s, qkv, dout, lse, delta, dqkv, cu_seqlens, work, T, D, H, scale, out);
+      else if (parts & 2)   // (the fragment-major kernel always derives delta: the register-staged one serves the two-stream form)
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<384, 1, false>), dim3(n_work * 2 * H), blk, 0, s, qkv, dout, lse, delta, dqkv, cu_seqlens, work, T, D, H, scale, out);
+      if (parts & 4)
+        hipLaunchKernelGGL((attn_bwd_dkv_dma_kernel<384, 1>), dim3(2 * n_work * H), blk, 0, s, qkv, dout, lse, delta, dqkv, cu_seqlens, work, T, D, H, scale);
+      break;
     default: return 2;
   }
-#undef BWD_CASE
+#undef BWD_REG_CASE
   CHADA_CHECK_LAUNCH();
   return 0;
 }

@@ -37,6 +37,10 @@ namespace {
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int TILE = 128;  // query rows per work item (the host's work list, chadavit_attn_tile_rows)
+#ifndef CHADA_M32_KV32
+#define CHADA_M32_KV32 0
+#endif
+constexpr bool KV32_AT_DH96 = CHADA_M32_KV32 != 0;   // 32-key tiles at dh 96 too: 24 KiB of LDS per block, five blocks per CU instead of three
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 constexpr float OVERFLOW_GUARD = 18446744073709551616.0f;  // 2^64: see SAFE
@@ -70,7 +74,7 @@ __device__ __forceinline__ float half_sum(float v) {
 
 template <int DH, int CB, int NW>
 struct Cfg {
-  static constexpr int KVT = (DH > 96) ? 32 : 64;   // keys per tile
+  static constexpr int KVT = (DH > 96 || KV32_AT_DH96) ? 32 : 64;   // keys per tile
   static constexpr int KS = DH / 16;                // 16-wide k-steps of S^T
   static constexpr int DB = DH / 32;                // 32-wide head-dim blocks of O^T
   static constexpr int KB = KVT / 32;               // 32-key blocks of S^T
@@ -283,7 +287,7 @@ __device__ __forceinline__ void fwd_item(BufRsrc qrs, bf16_t* smem, int len, int
 }
 
 template <int DH, int CB, int NW, int LEAN>
-__global__ __launch_bounds__(64 * NW, (CB > 1 ? 1 : (DH <= 96 ? 3 : 2))) void attn_fwd_m32_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(64 * NW, (CB > 1 ? 1 : (DH <= 96 ? (KV32_AT_DH96 ? 4 : 3) : 2))) void attn_fwd_m32_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                                                     float* __restrict__ lse, const int* __restrict__ cu,
                                                                                     const int* __restrict__ work, int T, int D, int H,
                                                                                     float scale) {

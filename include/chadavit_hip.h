@@ -264,7 +264,8 @@ int chadavit_attn_probs(const chada_bf16* qkv, float* probs, const int* cu_seqle
  * unless H != NULL (then relu(.) is also stored, M x FF, for the backward).  Replaces linear1 -> relu -> linear2 (+ residual
  * add) of torch.nn.TransformerEncoderLayer as built at src/backbones/vit/chada_vit.py:256-264.
  * `packed` is the fragment-major weight stream chadavit_ffn_pack builds from W1 [FF,D] and W2 [D,FF] (bf16);
- * chadavit_ffn_packed_bytes gives its size (-1 if the shape is unsupported).  rows_per_wave: 32 or 64. */
+ * chadavit_ffn_packed_bytes gives its size (-1 if the shape is unsupported).  rows_per_wave: kept in the signature; the kernel's own row
+ * tiling is used (32 rows per wave at D = 192, 16 at D = 384), 64 -- an instance removed in round 4 -- returns 2. */
 long long chadavit_ffn_packed_bytes(int D, int FF);
 int chadavit_ffn_pack(const chada_bf16* W1, const chada_bf16* W2, void* packed, int D, int FF, void* stream);
 int chadavit_ffn_fwd(const chada_bf16* X, int ldx, const void* packed, const float* b1, const float* b2,

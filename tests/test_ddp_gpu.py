@@ -318,7 +318,7 @@ def test_bench_contract_single_gpu_with_all_legs():
     cfg = out["config"]
     assert cfg["images_per_s_with_full_width_last_block"] > 0 and "workload" in cfg
     legs = cfg["other_workloads"]
-    assert set(legs) == {"cfg3", "cfg5", "cfg1", "cfg1-graph", "cfg2-1024"} and legs["cfg2-1024"]["images_per_gpu"] == 1024
+    assert set(legs) == {"cfg3", "cfg5", "cfg1", "cfg1-graph", "cfg2-1024", "cfg2-standard"} and legs["cfg2-1024"]["images_per_gpu"] == 1024
     for name, leg in legs.items():
         assert "error" not in leg, (name, leg)
         assert leg["images_per_s"] > 0 and leg["ms_per_step"] > 0

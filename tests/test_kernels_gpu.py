@@ -649,8 +649,8 @@ def test_lars_matches_oracle_and_golden():
                                        err_msg=f"{cname} {n}")
 
 
-@pytest.mark.parametrize("M,rpw,write_h,D", [(77, 32, True, 192), (1000, 32, False, 192), (1000, 64, True, 192), (4099, 32, True, 192),
-                                             (4099, 64, False, 192), (77, 32, True, 384), (1000, 32, False, 384), (4099, 32, True, 384)])
+@pytest.mark.parametrize("M,rpw,write_h,D", [(77, 32, True, 192), (1000, 32, False, 192), (4099, 32, True, 192),
+                                             (77, 32, True, 384), (1000, 32, False, 384), (4099, 32, True, 384)])
 def test_fused_ffn_matches_fp64_and_two_gemm_path(M, rpw, write_h, D):
     """ops.ffn_fwd (one kernel, hidden activation on chip) vs fp64 math and vs linear1 -> relu -> linear2 + residual as two
     GEMM launches (torch.nn.TransformerEncoderLayer feed-forward, chada_vit.py:256-264).  D = 384 (Small) is the second build of
