@@ -198,3 +198,24 @@ def test_device_prefetcher_plumbing_without_a_gpu():
     next(it); next(it)
     it.close()   # generator exit: the producer is told to stop and joined
     assert threading.active_count() <= n0
+
+
+def test_deferred_kernels_return_the_same_batch_and_a_launch_callable():
+    """DeviceMultiCropPipeline(..., defer=True) (DevicePrefetcher(kernels_on="consumer")): the call itself only prepares -- on the CPU
+    the kernels cannot run at all (no CPU fallback), so the deferred form must get through the host side and hand back the buffers, the
+    labels, the channel lists and ONE launch callable; the plain form must fail loudly in the first kernel."""
+    import pytest
+    from chadavit_amd.data.device_pipeline import CropSpec, DeviceMultiCropPipeline
+    rs = np.random.RandomState(0)
+    imgs = [rs.rand(c, 40, 48).astype(np.float32) for c in (2, 1)]
+    specs = [CropSpec(crop_size=32, num_crops=2, crop_min_scale=0.3, crop_max_scale=1.0, jitter_prob=0.8, blur_prob=0.5, flip_prob=0.5),
+             CropSpec(crop_size=16, num_crops=1, crop_min_scale=0.1, crop_max_scale=0.3)]
+    pipe = DeviceMultiCropPipeline(specs, "cpu", seed=3)
+    crops, lab, ncl, launch = pipe(imgs, labels=[4, 5], defer=True)
+    assert [tuple(c.shape) for c in crops] == [(3, 1, 32, 32), (3, 1, 32, 32), (3, 1, 16, 16)] and lab.tolist() == [4, 5] and ncl == [[2, 1]] * 3
+    assert crops[0].data_ptr() + crops[0].numel() * 4 == crops[1].data_ptr()     # crops of one resolution back to back (adjacent_view)
+    assert callable(launch) and len(pipe.last_params) == 3
+    with pytest.raises(Exception):
+        launch()                                       # the kernels need the GPU library's device path
+    with pytest.raises(Exception):
+        DeviceMultiCropPipeline(specs, "cpu", seed=3)(imgs)

@@ -198,6 +198,7 @@ def test_bench_contract_with_two_ranks():
     # (on by default when N > 1: no flag on the command line above)
     v = out["verify_equal_batch"]
     assert v["ok"] and v["rel_loss"] <= 3e-2 and v["rel_gradnorm"] <= 3e-2, v
+    assert v["sharded_step_repeats_bit_for_bit_on_every_rank"], v   # determinism with the collectives' traffic beside the kernels
     # how much of the gradient exchange was NOT hidden behind the backward, per rank, and each rank's own step time
     r = out["rccl"]
     assert len(r["exposed_ms_per_step_per_rank"]) == 2 and r["exposed_ms_per_step"] >= 0 and 0 <= r["exposed_fraction_of_step"] < 1

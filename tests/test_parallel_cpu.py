@@ -363,3 +363,67 @@ def test_linear_and_regression_host_logic():
         bad.optimizer.layer_decay = 0.75
         with pytest.raises(RuntimeError):
             LinearModel(bb, bad)
+
+
+def test_recorded_ragged_descriptions_outlive_the_cache():
+    """A captured hipGraph bakes in the addresses of the ragged index arrays: `recording_uses` hands every description used during
+    the capture to the graph's owner, so that the 8-entry cache forgetting them does not free them (advisor, round 3)."""
+    from chadavit_amd.ragged import _CACHE, _CACHE_MAX, ragged_batch, recording_uses
+    dev = torch.device("cpu")
+    owned = []
+    with recording_uses(owned):
+        a = ragged_batch([2, 1], 196, dev)
+        b = ragged_batch([2, 1], 36, dev)
+        assert ragged_batch([2, 1], 196, dev) is a      # a second use is not recorded twice
+    assert len(owned) == 2 and owned[0] is a and owned[1] is b
+    ragged_batch([5], 4, dev)                           # outside the context: not recorded
+    assert len(owned) == 2
+    for i in range(2 * _CACHE_MAX):                     # the cache forgets both ...
+        ragged_batch([i + 1], 9, dev)
+    assert all(v is not a and v is not b for v in _CACHE.values())
+    assert owned[0].cu_seqlens.tolist() == [0, 393, 590]   # ... the owner still holds them
+
+
+def _forced_worker(port, q):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", CHADAVIT_FORCE_COLLECTIVES="1")
+    import torch.distributed as dist
+    from chadavit_amd.parallel import SpanAllReduce, force_collectives, init_from_env
+    rank, world, _ = init_from_env("gloo")
+    ok = dist.is_initialized() and world == 1 and force_collectives()
+    red = SpanAllReduce()
+    ok = ok and red.active and red.world == 1
+    flat = torch.arange(100, dtype=torch.float32)
+    red.submit(flat, 10, 60)
+    red.finish()
+    ok = ok and len(red.spans) == 1 and torch.equal(flat, torch.arange(100, dtype=torch.float32))   # an identity at one rank
+    q.put(bool(ok))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_collectives_can_be_forced_in_a_group_of_one_rank():
+    """CHADAVIT_FORCE_COLLECTIVES=1: the process group is created at world size 1 and the gradient reducer issues its collectives
+    anyway (the GPU box runs the RCCL branches this way, tests/test_ddp_gpu.py::test_rccl_code_path_on_one_gpu); without the
+    switch a single rank stays collective-free."""
+    from chadavit_amd.parallel import SpanAllReduce
+    assert not SpanAllReduce().active
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_forced_worker, args=(_free_port(), q))
+    p.start()
+    assert q.get(timeout=100)
+    p.join(timeout=30)
+
+
+def test_dino_loss_module_accepts_the_standard_multicrop_view_count_and_checks_shapes():
+    """DINOLoss(num_large_crops=V): V student views as the reference's chunking arithmetic allows (losses/dino.py:82); fewer than the
+    teacher's two views is rejected, and so is a student tensor that is not V views of the teacher's images (checked before any kernel)."""
+    from chadavit_amd.losses.dino import DINOLoss
+    kw = dict(num_prototypes=64, warmup_teacher_temp=0.04, teacher_temp=0.07, warmup_teacher_temp_epochs=3, num_epochs=10)
+    assert DINOLoss(**kw).num_large_crops == 2 and DINOLoss(num_large_crops=10, **kw).num_large_crops == 10
+    with pytest.raises(RuntimeError):
+        DINOLoss(num_large_crops=1, **kw)
+    lf = DINOLoss(num_large_crops=5, **kw)
+    with pytest.raises(RuntimeError, match="5 views"):
+        lf(torch.zeros(8, 64), torch.zeros(4, 64))      # 8 rows are 4 views of 2 images, not 5
