@@ -10,8 +10,9 @@ student fwd+bwd on the 2 global crops, teacher fwd on the 2 global crops, studen
 
 Workload (default) = BASELINE.json configs[1]: ChAda-ViT-Tiny/16 (D 192, depth 12, 2 heads, FFN 2048),
 fixed 3-channel 224x224 synthetic images, 2 global (224) + 8 local (96) crops, head 2048/256/4096,
-bf16 storage / fp32 accumulate, 512 images per GPU (~60 GB of saved activations: sized for 288 GB HBM; 256/GPU -- the setting of
-round 1 and the first half of round 2 -- runs ~5 % slower per image, 128/GPU ~11 %; `--batch` selects).  Inputs are resident in HBM before the timed region.
+bf16 storage / fp32 accumulate, 1024 images per GPU since round 4 (~110 GB of the 288 GB HBM; step time is 7.4 ms + 0.175 ms per
+image, so 512/GPU -- rounds 2b-3's setting, still reported as the `cfg2-512` leg for like-for-like comparison -- runs 3 % slower per
+image, 256/GPU 8 %; same-box sweep in profiles/r04c_batch_sweep.txt; `--batch` selects).  Inputs are resident in HBM before the timed region.
 Prints ONE JSON line on rank 0 (contract in the task statement) including
   "roofline"     -- dominant kernel (largest share of GPU time among the instrumented entry points),
                     timed live with HIP events on the launch stream during the timed steps;
@@ -40,8 +41,9 @@ SUSTAINED_BF16_TFLOPS = 1750.0  # measured: what the MFMA pipes sustain on rando
 WORKLOADS = {
     # name: (embed_dim, channels spec, n_global, n_local, prototypes, per-GPU batch)
     "cfg2": dict(desc="ChAda-ViT-Tiny/16, fixed 3-channel 224x224, DINO 2 global + 8 local crops", D=192, channels="3",
-                 n_global=2, n_local=8, P=4096, batch=512),  # per-GPU images: 256 in rounds 1-2a; 512 uses ~50 of the 288 GB and amortises
-                 # the step's fixed ~5 ms (same box: 4521 / 4660 / 4743 images/s at 256 / 384 / 512; profiles/r02e_batch_sweep_cfg2.txt)
+                 n_global=2, n_local=8, P=4096, batch=1024),  # per-GPU images: 256 in rounds 1-2a, 512 in rounds 2b-3; 1024 uses ~110 of
+                 # the 288 GB and amortises the step's fixed ~7 ms further (same box: 5216 / 5306 / 5382 / 5443 / 5473 images/s at 512 / 768 /
+                 # 1024 / 1536 / 2048; profiles/r04c_batch_sweep.txt)
     # the north star's wording of the target ("Tiny/16 ... 1-10-channel multi-crop batches"): configs[1] with the channel mix of configs[2]
     "cfg2-mixed": dict(desc="ChAda-ViT-Tiny/16, variable 1-10 channel, DINO 2 global + 8 local crops", D=192, channels="1-10",
                        n_global=2, n_local=8, P=4096, batch=256),
@@ -962,10 +964,9 @@ def main():
             gc.collect()
             torch.cuda.empty_cache()
             legs = {}
-            # ("cfg2-1024": the headline workload at twice the images per GPU -- the per-step constants (optimiser, EMA, weight casts and
-            # packings, the heads) amortise further; informational, the headline stays at 512 per GPU for round-over-round comparisons)
+            # ("cfg2-512": the headline workload at rounds 2b-3's 512 images per GPU, for like-for-like comparison with their records)
             for name, kw in (("cfg3", {}), ("cfg5", {}), ("cfg1", {"steps": 30, "warmup": 3}), ("cfg1-graph", {"steps": 30, "warmup": 3, "graph": True}),
-                             ("cfg2-1024", {"steps": 4, "warmup": 2, "batch": 1024}), ("cfg2-standard", {"steps": 4, "warmup": 2, "wl_name": "cfg2-standard"})):
+                             ("cfg2-512", {"steps": 6, "warmup": 2, "batch": 512}), ("cfg2-standard", {"steps": 4, "warmup": 2, "wl_name": "cfg2-standard"})):
                 try:
                     legs[name] = other_workload_leg(kw.pop("wl_name", name.split("-")[0]), args, dev, **kw)
                 except Exception as e:  # noqa: BLE001 - the headline number must still be reported

@@ -301,7 +301,7 @@ def test_disk_to_training_step_on_two_ranks(tmp_path):
 @pytest.mark.timeout(1200)
 def test_bench_contract_single_gpu_with_all_legs():
     """`python bench.py` as the driver runs it at N = 1 (smaller batch, no CPU baseline): ONE JSON line with the contract's keys, the
-    roofline object, the full-width leg, the cfg3 / cfg5 / cfg1 (eager and hipGraph) / cfg2-at-1024 legs without an error entry, and the data-path
+    roofline object, the full-width leg, the cfg3 / cfg5 / cfg1 (eager and hipGraph) / cfg2-at-512 legs without an error entry, and the data-path
     leg.  Guards the round-end bench run against a leg that raises."""
     import json
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "32", "--no-cpu-baseline",
@@ -319,7 +319,7 @@ def test_bench_contract_single_gpu_with_all_legs():
     cfg = out["config"]
     assert cfg["images_per_s_with_full_width_last_block"] > 0 and "workload" in cfg
     legs = cfg["other_workloads"]
-    assert set(legs) == {"cfg3", "cfg5", "cfg1", "cfg1-graph", "cfg2-1024", "cfg2-standard"} and legs["cfg2-1024"]["images_per_gpu"] == 1024
+    assert set(legs) == {"cfg3", "cfg5", "cfg1", "cfg1-graph", "cfg2-512", "cfg2-standard"} and legs["cfg2-512"]["images_per_gpu"] == 512
     for name, leg in legs.items():
         assert "error" not in leg, (name, leg)
         assert leg["images_per_s"] > 0 and leg["ms_per_step"] > 0
