@@ -133,6 +133,7 @@ class DeviceMultiCropPipeline:
         self._staging: List[Optional[torch.Tensor]] = [None, None, None]
         self._staging_ev: List[Optional["torch.cuda.Event"]] = [None, None, None]
         self._calls = 0
+        self._copy_pool = None
 
     @property
     def num_crops(self) -> int:
@@ -203,8 +204,21 @@ class DeviceMultiCropPipeline:
         else:
             host = torch.empty(tot, dtype=torch.float32)
         hn = host.numpy()
-        for o, im in zip(offs, planes):
-            hn[o:o + im.size] = im.reshape(-1)
+        # the raw planes into the pinned staging buffer: 0.8 MB per 3-channel 256 x 256 image, 0.8 GB per 1024-image batch -- one memcpy
+        # stream from the producer thread was the slowest stage of the path (~100 ms per batch); numpy releases the GIL inside large
+        # copies, so a few helper threads run them side by side
+        def put(lo, hi):
+            for o, im in zip(offs[lo:hi], planes[lo:hi]):
+                hn[o:o + im.size] = im.reshape(-1)
+        n_img = len(planes)
+        if tot >= (1 << 24) and n_img >= 16:
+            if self._copy_pool is None:
+                from concurrent.futures import ThreadPoolExecutor
+                self._copy_pool = ThreadPoolExecutor(max_workers=8, thread_name_prefix="chadavit-stage")
+            step = (n_img + 7) // 8
+            list(self._copy_pool.map(lambda lo: put(lo, min(lo + step, n_img)), range(0, n_img, step)))
+        else:
+            put(0, n_img)
         src = host.to(self.device, non_blocking=True)
         if self.device.type == "cuda":
             self._staging_ev[k] = torch.cuda.Event()

@@ -22,7 +22,7 @@ for n, c in agg.items():
     for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_INST_CYCLES_VMEM"):
         if k in v: print("  %-22s %.3g  (%.1f%% of wave cycles)" % (k, v[k], 100 * v[k] / wc))
     if "SQ_VALU_MFMA_BUSY_CYCLES" in v: print("  MFMA busy frac %.3f" % (v["SQ_VALU_MFMA_BUSY_CYCLES"] / (busy * 32)))
-    if "SQ_LDS_BANK_CONFLICT" in v and "SQ_LDS_IDX_ACTIVE" in v: print("  LDS bank conflict frac %.3f  (conflict %.3g / active %.3g)" % (v["SQ_LDS_BANK_CONFLICT"] / v["SQ_LDS_IDX_ACTIVE"], v["SQ_LDS_BANK_CONFLICT"], v["SQ_LDS_IDX_ACTIVE"]))
+    if "SQ_LDS_BANK_CONFLICT" in v and v.get("SQ_LDS_IDX_ACTIVE"): print("  LDS bank conflict frac %.3f  (conflict %.3g / active %.3g)" % (v["SQ_LDS_BANK_CONFLICT"] / v["SQ_LDS_IDX_ACTIVE"], v["SQ_LDS_BANK_CONFLICT"], v["SQ_LDS_IDX_ACTIVE"]))
     if "FETCH_SIZE" in v: print("  FETCH %.1f MB (x2 corr %.1f)  WRITE %.1f MB" % (v["FETCH_SIZE"] / 1024, v["FETCH_SIZE"] / 512, v.get("WRITE_SIZE", 0) / 1024))
     for k in ("SQ_INSTS_LDS", "SQ_INSTS_VALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SALU", "SQ_INSTS_MFMA", "SQ_INSTS_VALU_MFMA_MOPS_BF16"):
         if k in v: print("  %-22s %.4g" % (k, v[k]))
