@@ -501,6 +501,7 @@ class DINO(_Base):
             self.list_num_channels = list_num_channels = [list_num_channels]
         assert len(X) == self.num_crops
         self.head.skip_last_layer_grad = self.current_epoch < self.freeze_last_layer
+        self.backbone._pending_backwards = 0   # (2 only in the standard multi-crop option below; a step that raised must not leave it set)
         nl = self.num_large_crops
         same_size = all(x.shape[-1] == X[0].shape[-1] for x in X[:nl])
         # Independent passes run on side HIP streams so their kernels fill each other's grid tails (a 1178-tile grid is
