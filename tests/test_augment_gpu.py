@@ -134,3 +134,32 @@ def test_pipeline_feeds_the_training_step():
     g, l = adjacent_view(crops[:2]), adjacent_view(crops[2:])
     assert g is not None and l is not None and g.data_ptr() == crops[0].data_ptr()
     assert torch.equal(g, torch.cat(crops[:2])) and torch.equal(l, torch.cat(crops[2:]))
+
+
+def test_prefetcher_kernel_placements_give_identical_batches():
+    """DevicePrefetcher(kernels_on="producer") -- augmentation kernels beside the step on the prefetcher's stream -- and
+    kernels_on="consumer" -- only the copies run ahead, the kernels are launched at the head of the consumer's stream when the batch is
+    handed over -- must hand out bit-identical crops (same seeds, same descriptors, same kernels; only the stream differs), also while the
+    consumer's stream is busy and the allocator re-issues blocks between batches."""
+    from chadavit_amd.data.device_pipeline import CropSpec, DeviceMultiCropPipeline
+    from chadavit_amd.data.loader import DevicePrefetcher, InMemoryPlanes
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(3)
+    ds = InMemoryPlanes([rs.rand(c, 72, 80).astype(np.float32) for c in (3, 1, 2, 5, 1, 3, 2, 4, 1, 2, 3, 1)])
+    batches = [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10, 11], [3, 2, 1, 0]]
+    specs = [CropSpec(64, 2, jitter_prob=0.8, blur_prob=0.6, solarize_prob=0.3, flip_prob=0.5),
+             CropSpec(32, 3, crop_min_scale=0.05, crop_max_scale=0.3, jitter_prob=0.8, blur_prob=0.5, flip_prob=0.5)]
+    got = {}
+    for mode in ("producer", "consumer"):
+        out = []
+        for crops, lab, ncl in DevicePrefetcher(ds, batches, DeviceMultiCropPipeline(specs, dev, seed=11), depth=2, workers=3, kernels_on=mode):
+            busy = torch.randn(2048, 2048, device=dev) @ torch.randn(2048, 2048, device=dev)   # keeps the consumer's stream occupied
+            out.append(([c.clone() for c in crops], lab.clone(), ncl))
+            del busy
+        torch.cuda.synchronize()
+        got[mode] = out
+    assert len(got["producer"]) == len(got["consumer"]) == 4
+    for (ca, la, na), (cb, lb, nb) in zip(got["producer"], got["consumer"]):
+        assert na == nb and torch.equal(la, lb) and len(ca) == len(cb) == 5
+        for a, b in zip(ca, cb):
+            assert torch.isfinite(a).all() and torch.equal(a, b)
