@@ -55,9 +55,13 @@ class DINOLoss(nn.Module):
         # temp_dev: a device float32[1] holding the teacher temperature of this epoch (chadavit_amd.graphed: the captured step reads
         # it from memory instead of freezing the value into the graph)
         temp = self.temp_dev if self.temp_dev is not None else float(self.teacher_temp_schedule[self.epoch])
-        if student_output.shape[0] * 2 != teacher_output.shape[0] * self.num_large_crops:
-            raise RuntimeError(f"DINOLoss: {student_output.shape[0]} student rows are not {self.num_large_crops} views of the "
-                               f"{teacher_output.shape[0] // 2} images the teacher saw")
+        # the student's rows are `num_large_crops` views of the teacher's images -- or just the 2 global views (validation_step feeds
+        # those alone, dino.py:327-365, whatever the training loss is built over)
+        n_img = teacher_output.shape[0] // 2
+        views = student_output.shape[0] // max(n_img, 1)
+        if n_img * 2 != teacher_output.shape[0] or views * n_img != student_output.shape[0] or views not in (2, self.num_large_crops):
+            raise RuntimeError(f"DINOLoss: {student_output.shape[0]} student rows are not {self.num_large_crops} views (or the 2 global "
+                               f"views) of the {n_img} images the teacher saw")
         self.sync_center()  # the previous step's centre update (its all-reduce ran beside that step's backward)
         loss, colsum = _DinoLossFn.apply(student_output, teacher_output, self.center, float(self.student_temp), temp)
         self.update_center(teacher_output, colsum)

@@ -426,4 +426,6 @@ def test_dino_loss_module_accepts_the_standard_multicrop_view_count_and_checks_s
         DINOLoss(num_large_crops=1, **kw)
     lf = DINOLoss(num_large_crops=5, **kw)
     with pytest.raises(RuntimeError, match="5 views"):
-        lf(torch.zeros(8, 64), torch.zeros(4, 64))      # 8 rows are 4 views of 2 images, not 5
+        lf(torch.zeros(8, 64), torch.zeros(4, 64))      # 8 rows are 4 views of 2 images, not 5 (and not the 2 global views)
+    with pytest.raises(RuntimeError, match="5 views"):
+        lf(torch.zeros(9, 64), torch.zeros(4, 64))      # not a whole number of views
