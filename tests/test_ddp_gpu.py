@@ -34,6 +34,8 @@ imgs = [imgs_all[i] for i in mine]
 crops, labels, ncl = one_channel_collate_fn(imgs)
 batch = ([c.to(dev) for c in crops], labels.to(dev), ncl)
 cfg = _cfg(192, 4096, 2, 1)
+if os.environ.get("CHADAVIT_TEST_STANDARD_MULTICROP"):   # the flagged standard-DINO option: two backward passes per network and step
+    cfg.method_kwargs.standard_multicrop_loss = True
 model = DINO(cfg)
 sd = build_sd(192, 4096)
 if rank != 0:   # non-zero ranks start from different weights: the broadcast must fix that
@@ -65,9 +67,9 @@ if world > 1:
 '''
 
 
-def _run(world, worker=None):
+def _run(world, worker=None, extra_env=None):
     worker = WORKER if worker is None else worker
-    env = dict(os.environ, CHADAVIT_ROOT=ROOT, PYTHONPATH=ROOT)
+    env = dict(os.environ, CHADAVIT_ROOT=ROOT, PYTHONPATH=ROOT, **(extra_env or {}))
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     if world == 1:
         cmd = [sys.executable, "-c", worker]
@@ -99,6 +101,21 @@ def test_two_ranks_match_single_process():
     assert abs(one["center"] - two["center"]) <= 1e-3 * abs(one["center"]) + 1e-4
     # ... although with two ranks its all-reduce was still in flight when the step returned (finished by sync_center)
     assert two["center_pending_after_step"] and not one["center_pending_after_step"]
+    for a, b in zip(one["g0"], two["g0"]):
+        assert abs(a - b) <= 3e-2 * max(abs(a), abs(b)) + 5e-4
+
+
+@pytest.mark.timeout(1500)
+def test_two_ranks_match_single_process_with_the_standard_multicrop_loss():
+    """The flagged standard-DINO option under data parallelism: every network runs TWO backward passes per step (global-crop pass,
+    local-crop pass) that accumulate into one gradient slab; the per-block gradient spans may go to the reducer only during the LAST of
+    them (`_pending_backwards`), or half-finished sums would be averaged.  World 2 vs world 1 on the same global batch, as above."""
+    env = {"CHADAVIT_TEST_STANDARD_MULTICROP": "1"}
+    one = _run(1, extra_env=env)
+    two = _run(2, extra_env=env)
+    for n, v in one["gnorm"].items():
+        assert abs(two["gnorm"][n] - v) <= 3e-2 * v + 1e-7, (n, v, two["gnorm"][n])
+    assert abs(one["center"] - two["center"]) <= 1e-3 * abs(one["center"]) + 1e-4
     for a, b in zip(one["g0"], two["g0"]):
         assert abs(a - b) <= 3e-2 * max(abs(a), abs(b)) + 5e-4
 
