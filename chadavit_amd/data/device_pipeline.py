@@ -78,15 +78,22 @@ class CropSpec:
 
 
 def rrc_box(H: int, W: int, scale, ratio, rng: random.Random) -> Tuple[int, int, int, int]:
-    """(y0, x0, h, w): albumentations 1.3.1 RandomResizedCrop parameter draw (10 attempts, central fallback)."""
+    """(y0, x0, h, w): albumentations 1.3.1 RandomResizedCrop parameter draw (10 attempts, central fallback).
+    (Hot on the producer thread -- 10 crops x batch size calls per batch: `uniform` / `randint` are written out as the arithmetic
+    `random.Random` performs on the same draws, `a + (b - a) * random()` and `_randbelow(n + 1)`: same stream, same values.)"""
     area = H * W
+    rnd, below = rng.random, rng._randbelow
+    s0, ds = scale[0], scale[1] - scale[0]
+    l0 = math.log(ratio[0])
+    dl = math.log(ratio[1]) - l0
+    sqrt, exp = math.sqrt, math.exp
     for _ in range(10):
-        target_area = rng.uniform(*scale) * area
-        aspect = math.exp(rng.uniform(math.log(ratio[0]), math.log(ratio[1])))
-        w = int(round(math.sqrt(target_area * aspect)))
-        h = int(round(math.sqrt(target_area / aspect)))
+        target_area = (s0 + ds * rnd()) * area
+        aspect = exp(l0 + dl * rnd())
+        w = int(round(sqrt(target_area * aspect)))
+        h = int(round(sqrt(target_area / aspect)))
         if 0 < w <= W and 0 < h <= H:
-            i, j = rng.randint(0, H - h), rng.randint(0, W - w)
+            i, j = below(H - h + 1), below(W - w + 1)
             return int((H - h) * (i * 1.0 / (H - h + 1e-10))), int((W - w) * (j * 1.0 / (W - w + 1e-10))), h, w
     in_ratio = W / H
     if in_ratio < min(ratio):
@@ -147,32 +154,49 @@ class DeviceMultiCropPipeline:
         its `p` is never consulted and no draw is consumed: with `color_jitter.prob` non-zero EVERY crop is jittered (the
         shipped 0.8 behaves as 1.0).  Reproduced as is."""
         p = CropParams()
+        rng = self.rng
+        rnd = rng.random
+        if spec.jitter_prob:
+            # numpy's stream, the samples' (shifts, gammas) pairs in order: ONE block of uniform doubles, cut as the per-sample
+            # `uniform(lo, hi, C)` calls would consume it (lo + (hi - lo) * u, RandomState's own arithmetic) -- same values, one call
+            # instead of two per sample
+            u = self.np_rng.random_sample(2 * sum(s_[0] for s_ in shapes))
+            slo, sd = spec.int_min_shift, spec.int_max_shift - spec.int_min_shift
+            glo, gd = spec.gamma_min, spec.gamma_max - spec.gamma_min
+            o = 0
+            for (C, _, _) in shapes:
+                p.shifts.append(slo + sd * u[o:o + C])
+                p.gammas.append(glo + gd * u[o + C:o + 2 * C])
+                o += 2 * C
+        else:
+            p.shifts = [None] * len(shapes)
+            p.gammas = [None] * len(shapes)
+        scale = (spec.crop_min_scale, spec.crop_max_scale)
+        gray_p, blur_p, sol_p, flip_p, norm_on, norm_p = spec.gray_prob, spec.blur_prob, spec.solarize_prob, spec.flip_prob, spec.normalize is not None, spec.normalize_prob
+        boxes, grays, blurs, sols, flips, normed = p.boxes, p.grays, p.blurs, p.solarize, p.flips, p.normalized
         for (C, H, W) in shapes:
-            self.rng.random()  # RandomResizedCrop / Resize: p = 1.0, the draw still happens (BasicTransform.__call__)
-            p.boxes.append(rrc_box(H, W, (spec.crop_min_scale, spec.crop_max_scale), spec.ratio, self.rng) if spec.rrc_enabled else (0, 0, H, W))
-            if spec.jitter_prob:   # in the list at all <=> prob != 0 (pretrain_dataloader.py:301); then unconditional, no draw
-                p.shifts.append(self.np_rng.uniform(spec.int_min_shift, spec.int_max_shift, C))
-                p.gammas.append(self.np_rng.uniform(spec.gamma_min, spec.gamma_max, C))
-            else:
-                p.shifts.append(None); p.gammas.append(None)
-            gray = bool(spec.gray_prob and self.rng.random() < spec.gray_prob)
+            rnd()  # RandomResizedCrop / Resize: p = 1.0, the draw still happens (BasicTransform.__call__)
+            boxes.append(rrc_box(H, W, scale, spec.ratio, rng) if spec.rrc_enabled else (0, 0, H, W))
+            # (the jitter sits here in the reference's list: in it at all <=> prob != 0 (pretrain_dataloader.py:301), then unconditional and
+            #  without a draw from THIS stream -- its numpy draws were taken above)
+            gray = bool(gray_p and rnd() < gray_p)
             if gray and C != 3:
                 raise RuntimeError(f"ToGray fired on a {C}-channel sample: albumentations raises TypeError there (3-channel images only)")
-            p.grays.append(gray)
-            if spec.blur_prob and self.rng.random() < spec.blur_prob:
-                k = self.rng.randrange(spec.blur_limit[0], spec.blur_limit[1] + 1)
+            grays.append(gray)
+            if blur_p and rnd() < blur_p:
+                k = rng.randrange(spec.blur_limit[0], spec.blur_limit[1] + 1)
                 if k != 0 and k % 2 != 1:
                     k = (k + 1) % (spec.blur_limit[1] + 1)
-                p.blurs.append((k, self.rng.uniform(*spec.sigma_limit)))
+                blurs.append((k, rng.uniform(*spec.sigma_limit)))
             else:
-                p.blurs.append(None)
-            if spec.solarize_prob and self.rng.random() < spec.solarize_prob:
-                p.solarize.append(self.rng.uniform(spec.solarize_threshold, spec.solarize_threshold))
+                blurs.append(None)
+            if sol_p and rnd() < sol_p:
+                sols.append(rng.uniform(spec.solarize_threshold, spec.solarize_threshold))
             else:
-                p.solarize.append(None)
-            p.flips.append(bool(spec.flip_prob and self.rng.random() < spec.flip_prob))
-            self.rng.random()  # ToTensorV2(always_apply=True): `random.random() < p or always_apply` still draws
-            p.normalized.append(bool(spec.normalize is not None and self.rng.random() < spec.normalize_prob))
+                sols.append(None)
+            flips.append(bool(flip_p and rnd() < flip_p))
+            rnd()  # ToTensorV2(always_apply=True): `random.random() < p or always_apply` still draws
+            normed.append(bool(norm_on and rnd() < norm_p))
         return p
 
     def __call__(self, images: Sequence[np.ndarray], labels: Optional[Sequence[int]] = None, params: Optional[List[CropParams]] = None,
@@ -295,13 +319,17 @@ class DeviceMultiCropPipeline:
             fin[:, 9] = spec.solarize_max
             fin[:, 11] = 1.0
             if has_blur.any():
+                # gaussian_taps for all blurred samples at once (same arithmetic: float64 exponentials, normalised, rounded to float32)
+                idx = np.nonzero(has_blur)[0]
+                ks = np.fromiter((cp.blurs[i][0] for i in idx), dtype=np.int64, count=len(idx))
+                sg = np.fromiter((cp.blurs[i][1] for i in idx), dtype=np.float64, count=len(idx))
+                if ks.max() > 7:
+                    raise RuntimeError("GaussianBlur kernel sizes above 7 are not supported on the device path")
+                t = np.arange(7, dtype=np.float64)[None, :] - (ks[:, None] - 1) / 2.0
+                kk = np.where(np.arange(7)[None, :] < ks[:, None], np.exp(-(t * t) / (2.0 * sg[:, None] * sg[:, None])), 0.0)
                 rows = np.zeros((n, 8), dtype=np.float32)
-                for i in np.nonzero(has_blur)[0]:
-                    k, sg = cp.blurs[i]
-                    if k > 7:
-                        raise RuntimeError("GaussianBlur kernel sizes above 7 are not supported on the device path")
-                    rows[i, 0] = k
-                    rows[i, 1:8] = gaussian_taps(k, sg)
+                rows[idx, 0] = ks
+                rows[idx, 1:8] = (kk / kk.sum(1, keepdims=True)).astype(np.float32)
                 fin[:, 0:8] = np.repeat(rows, C, axis=0)
             if has_sol.any():
                 fin[:, 8] = rep(np.asarray([np.inf if t is None else t for t in cp.solarize], dtype=np.float32))
