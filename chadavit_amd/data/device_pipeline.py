@@ -295,6 +295,8 @@ class DeviceMultiCropPipeline:
         H = np.fromiter((s_[1] for s_ in shapes), dtype=np.int64, count=n)
         W = np.fromiter((s_[2] for s_ in shapes), dtype=np.int64, count=n)
         off = np.asarray(offs, dtype=np.int64)
+        if n and int((H * W).max()) >= 1 << 30:
+            raise RuntimeError("source planes of 2^30 pixels or more are not supported (chadavit_crop_resize addresses a crop window with 32-bit byte offsets)")
         normed = np.asarray(cp.normalized if cp.normalized else [spec.normalize is not None] * n, dtype=bool)
         grays = cp.grays if cp.grays else [False] * n
         has_blur = np.fromiter((b is not None and b[0] > 1 for b in cp.blurs), dtype=bool, count=n)

@@ -6,9 +6,9 @@ The reference feeds its step from `DataLoader(dataset, collate_fn=one_channel_co
 Here the workers only DECODE (`dataset.read_planes`, PIL releases the GIL); everything after that -- the copy of the raw planes and
 the crop / jitter / blur kernels of `DeviceMultiCropPipeline` -- runs on the GPU, on a stream of its own, `depth` batches ahead, while
 the previous step computes.  The consumer orders itself behind a batch with one event wait; nothing blocks the host.
-`kernels_on="consumer"` moves the augmentation KERNELS (not the copies) to the head of the consumer's stream instead -- measured in
-round 4 and not the default: the cfg2 step fed that way ran at 0.928 of the same steps on a resident batch, against 0.967 with the kernels
-beside the step on the side stream (they take ~7 ms serial per 512-image batch and mostly fit into the step's own slack).
+`kernels_on="consumer"` moves the augmentation KERNELS (not the copies) to the head of the consumer's stream instead.  Not the default:
+with the round-4 kernels (3.2 ms per 1 024-image 10-crop batch) the cfg2 step fed either way runs at 0.98 of the same steps on a resident
+batch (producer 0.979, consumer 0.976; profiles/r04f_*); with the slower first kernels the side stream hid more of them.
 
     ds = IDRCell100K(root_dir=..., train=True)
     sampler = TokenBalancedBatchSampler(ds.num_channels(), global_batch, rank, world)
@@ -28,14 +28,15 @@ import torch
 
 class DevicePrefetcher:
     def __init__(self, dataset, batch_sampler: Iterable[Sequence[int]], pipeline, depth: int = 2, workers: int = 8,
-                 labels: Optional[Sequence[int]] = None, kernels_on: str = "producer"):
+                 labels: Optional[Sequence[int]] = None, kernels_on: str = "producer", stream: Optional["torch.cuda.Stream"] = None):
         if kernels_on not in ("consumer", "producer"):
             raise ValueError("kernels_on: 'consumer' or 'producer'")
         self.defer = kernels_on == "consumer" and pipeline.device.type == "cuda"
         self.dataset, self.batch_sampler, self.pipeline = dataset, batch_sampler, pipeline
         self.depth, self.workers, self.labels = max(1, depth), max(1, workers), labels
         self.device = pipeline.device
-        self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        # stream: the side stream to produce on (default: a new one at the default priority)
+        self.stream = (stream if stream is not None else torch.cuda.Stream(device=self.device)) if self.device.type == "cuda" else None
         self.read_s = 0.0      # host seconds spent decoding (sum over batches; the reader threads' wall time per batch)
         self.batches = 0
 

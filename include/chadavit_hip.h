@@ -381,10 +381,11 @@ int chadavit_gemm_nt_mx8_q(const void* Xq, const void* xs, int lds_x, const void
  * chadavit_crop_resize: RandomResizedCrop / Resize with cv2.INTER_CUBIC (+ CustomColorJitter, src/data/custom_transforms.py:301-351,
  *   + HorizontalFlip) of n_channel_images source planes into out [n_channel_images, S, S] fp32 = the (sum C, 1, S, S) collate layout of
  *   src/data/channels_strategies.py:31-85.  desc: 8 long long per OUTPUT channel image = {element offset of the source plane in src,
- *   H, W, x0, y0, crop_w, crop_h, flip}; shift / gamma: per channel image (gamma < 0: no jitter for it), or both NULL.
+ *   H, W, x0, y0, crop_w, crop_h, flip}; shift / gamma: per channel image (gamma < 0: no jitter for it), or both NULL.  S <= 1024
+ *   (return 2 above that); a crop window must span less than 2^32 bytes of its source plane (32-bit offsets from its corner).
  * chadavit_blur_finish: GaussianBlur (BORDER_REFLECT_101) -> Solarize -> Normalize, out != in; fin: 12 floats per channel image =
  *   {ksize (0/1 = no blur, <= 7), 7 centred 1-D taps, solarize threshold (+inf = off), solarize max, mean * max_pixel_value,
- *   1 / (std * max_pixel_value)}. */
+ *   1 / (std * max_pixel_value)}.  4 <= S <= 1024. */
 int chadavit_crop_resize(const float* src, const long long* desc, const float* shift, const float* gamma, float* out,
                          int n_channel_images, int S, void* stream);
 int chadavit_blur_finish(const float* in, const float* fin, float* out, int n_channel_images, int S, void* stream);
