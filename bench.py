@@ -678,7 +678,7 @@ def other_workload_leg(name, args, dev, steps=3, warmup=2, graph=False, batch=No
     return res
 
 
-def data_path_leg(wl, args, dev, tr, steps=6, n_samples=1536, side=256, workers=32):
+def data_path_leg(wl, args, dev, tr, steps=8, n_samples=1536, side=256, workers=32):
     """SURVEY 8(f)2 throughput: can the device data path feed the step?  Synthetic raw planes (C x side x side float32, the channel
     mix of the workload) held in host memory stand for decoded images; the decode itself is timed separately on a small on-disk
     IDRCell100k-format set (PNG, one file per channel).  Three numbers: decode images/s per reader thread, the pipeline alone
