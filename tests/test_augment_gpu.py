@@ -72,6 +72,53 @@ def test_device_multicrop_matches_oracle_and_collate_layout():
     assert ncl2 == ncl and all(torch.equal(a, b.cpu()) for a, b in zip(cc, crops))
 
 
+def _against_oracle(pipe, imgs, atol=2e-5):
+    """Every crop of `pipe(imgs)` against oracle/augment_ref.augment_plane on the parameters the pipeline drew."""
+    crops, _, _ = pipe(imgs)
+    crops = crops if isinstance(crops, (list, tuple)) else [crops]
+    k = 0
+    for spec in pipe.specs:
+        for _ in range(spec.num_crops):
+            cp = pipe.last_params[k]
+            ref = np.stack([A.augment_plane(im[c], spec.crop_size, cp.boxes[i], None if cp.shifts[i] is None else cp.shifts[i][c],
+                                            None if cp.gammas[i] is None else cp.gammas[i][c], cp.flips[i], cp.blurs[i], cp.solarize[i], None)
+                            for i, im in enumerate(imgs) for c in range(im.shape[0])])[:, None]
+            np.testing.assert_allclose(crops[k].cpu().numpy(), ref, atol=atol, rtol=0)
+            k += 1
+    return crops
+
+
+def test_every_path_of_the_resize_and_blur_kernels_vs_oracle():
+    """chadavit_crop_resize stages the source rows of a band of output rows in LDS when they fit 32 KB and reads its taps from global
+    memory otherwise; chadavit_blur_finish has a quad path (S % 4 == 0, aligned) and an element path.  Each of them, plus the size-preserving
+    copy path, small and odd output sizes, flips and every blur width, against the oracle's restatement of cv2's arithmetic."""
+    from chadavit_amd.data.device_pipeline import CropSpec, DeviceMultiCropPipeline
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(7)
+    # large planes scaled down by 3-5x: a 16-row band of a 224-pixel crop needs ~70 source rows of 700-1000 pixels -> the global-tap path
+    big = [rs.rand(2, 700, 900).astype(np.float32), rs.rand(1, 1024, 1000).astype(np.float32)]
+    _against_oracle(DeviceMultiCropPipeline([CropSpec(224, 2, crop_min_scale=0.5, crop_max_scale=1.0, jitter_prob=0.8, blur_prob=1.0, flip_prob=0.5),
+                                             CropSpec(96, 1, crop_min_scale=0.3, crop_max_scale=1.0, blur_prob=0.5, flip_prob=0.5),
+                                             CropSpec(97, 1, crop_min_scale=0.5, crop_max_scale=1.0, blur_prob=1.0, flip_prob=0.5)], dev, seed=2), big)
+    # small planes scaled up and down around 1x: the LDS-staged path; odd and tiny output sizes: the element paths of both kernels
+    small = _batch(4)
+    _against_oracle(DeviceMultiCropPipeline([CropSpec(224, 1, crop_min_scale=0.25, crop_max_scale=1.0, jitter_prob=0.8, blur_prob=1.0, flip_prob=0.5),
+                                             CropSpec(96, 2, crop_min_scale=0.05, crop_max_scale=0.25, jitter_prob=0.8, blur_prob=1.0, flip_prob=0.5),
+                                             CropSpec(30, 1, crop_min_scale=0.1, crop_max_scale=1.0, blur_prob=1.0, flip_prob=0.5),
+                                             CropSpec(9, 1, blur_prob=1.0), CropSpec(8, 1, jitter_prob=0.8, blur_prob=1.0), CropSpec(5, 1, blur_prob=1.0),
+                                             CropSpec(512, 1, jitter_prob=0.8, blur_prob=1.0, flip_prob=0.5)], dev, seed=3), small)
+    # size-preserving Resize (cv2.resize returns a copy): 224-pixel planes without RandomResizedCrop, with and without a flip
+    same = [rs.rand(3, 224, 224).astype(np.float32), rs.rand(1, 224, 224).astype(np.float32)]
+    crops = _against_oracle(DeviceMultiCropPipeline([CropSpec(224, 2, rrc_enabled=False, flip_prob=0.5, jitter_prob=0.8)], dev, seed=1), same, atol=1e-6)
+    assert len(crops) == 2
+    # limits of the entry points: loud, not silent
+    from chadavit_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.blur_finish(torch.zeros(1, 1, 2, 2, device=dev), torch.zeros(1, 12, device=dev))          # S < 4
+    with pytest.raises(RuntimeError):
+        ops.crop_resize(torch.zeros(16, device=dev), torch.tensor([[0, 4, 4, 0, 0, 4, 4, 0]], device=dev), 1028)   # S > 1024
+
+
 def test_gray_and_draw_order_on_three_channel_samples():
     """A.ToGray (pretrain_dataloader.py:303-304) on 3-channel samples, between the jitter and the blur; it raises on any other
     channel count when it fires, as albumentations does.  Also pins the number of Python-`random` draws per sample against the
