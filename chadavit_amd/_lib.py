@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # CHADAVIT_HIP_LIB: load another build of the same ABI instead (same-box A/B of kernel variants; see scratch/)
 LIB_PATH = os.environ.get("CHADAVIT_HIP_LIB") or os.path.join(HERE, "libchadavit_hip.so")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "chadavit_hip.h")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class HipExtensionMissing(RuntimeError):

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libchadavit_hip.so")
-SOURCES = ["gemm_nt.hip", "ffn_fused.hip", "ffn_fused_d384.hip", "gemm_tn.hip", "layernorm.hip", "attention.hip", "attention_m32.hip", "attention_bwd_m32.hip", "attention_cls.hip", "tokenizer.hip", "dino_ops.hip", "gemm_mx8.hip", "augment.hip"]
+SOURCES = ["gemm_nt.hip", "ffn_fused.hip", "ffn_fused_d384.hip", "gemm_tn.hip", "layernorm.hip", "attention.hip", "attention_m32.hip", "attention_bwd_m32.hip", "attention_cls.hip", "tokenizer.hip", "dino_ops.hip", "gemm_mx8.hip", "augment.hip", "host_draw.hip"]
 # -packed-fp32-ops: no v_pk_{mul,add,fma}_f32.  On gfx950 a packed f32 op costs the VALU port 8 cycles -- the same as the two scalar ops it
 # replaces -- and beside MFMAs it stalls the matrix pipe on top (scratch/r3/coissue*.hip: 2 v_pk_fma_f32 per 32x32x16 MFMA = 60 cycles per
 # MFMA against 36 with 2 v_fma_f32).  hipcc forms them from every float4 / float2 expression.  Same-box A/B of the whole step: +1.2 %

@@ -18,6 +18,7 @@ training contract needs.  ToGray / Equalize of the reference pipeline require 3-
 from __future__ import annotations
 
 import contextlib
+import ctypes
 import math
 import random
 from dataclasses import dataclass, field
@@ -26,7 +27,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-from .. import ops
+from .. import _lib, ops
 
 
 @dataclass
@@ -126,6 +127,22 @@ class CropParams:
     flips: List[bool] = field(default_factory=list)
     grays: List[bool] = field(default_factory=list)                          # per image: ToGray fired
     normalized: List[bool] = field(default_factory=list)                     # per image: Normalize fired (p = normalize_prob)
+    arrays: Optional[dict] = field(default=None, repr=False, compare=False)  # the same draws as numpy arrays (the C draw's outputs), if they exist
+    jitter_flat: Optional[tuple] = field(default=None, repr=False, compare=False)  # (shifts, gammas) of all channel images in one array each
+
+
+class _Geometry:
+    """Per-batch index arrays shared by the ten crops of a batch: C / H / W per sample, cumulative channel count with a leading 0, channel
+    index inside its sample per channel image."""
+    __slots__ = ("n", "C", "H", "W", "hw", "cum", "chan")
+
+    def __init__(self, shapes):
+        n = self.n = len(shapes)
+        a = np.asarray(shapes, dtype=np.int64).reshape(n, 3)
+        self.C, self.H, self.W = a[:, 0].copy(), a[:, 1].copy(), a[:, 2].copy()
+        self.hw = np.ascontiguousarray(a[:, 1:3])
+        self.cum = np.concatenate([[0], np.cumsum(self.C)])
+        self.chan = np.arange(int(self.cum[-1]), dtype=np.int64) - np.repeat(self.cum[:-1], self.C)
 
 
 class DeviceMultiCropPipeline:
@@ -141,12 +158,13 @@ class DeviceMultiCropPipeline:
         self._staging_ev: List[Optional["torch.cuda.Event"]] = [None, None, None]
         self._calls = 0
         self._copy_pool = None
+        self.python_draws = False   # True: the per-sample draw loop in Python even for a plain random.Random (A/B, tests)
 
     @property
     def num_crops(self) -> int:
         return sum(s.num_crops for s in self.specs)
 
-    def _draw(self, spec: CropSpec, shapes: Sequence[Tuple[int, int, int]]) -> CropParams:
+    def _draw(self, spec: CropSpec, shapes: Sequence[Tuple[int, int, int]], geo: Optional[_Geometry] = None) -> CropParams:
         """The random parameters of one crop of every sample, drawn in the order albumentations 1.3.1 consumes Python's `random`
         inside `Compose.__call__` for the reference's list (pretrain_dataloader.py:281-326).  Every `BasicTransform.__call__`
         evaluates `random.random() < p` first -- also for p = 1.0 and for always_apply transforms (ToTensorV2) --, EXCEPT the
@@ -154,23 +172,27 @@ class DeviceMultiCropPipeline:
         its `p` is never consulted and no draw is consumed: with `color_jitter.prob` non-zero EVERY crop is jittered (the
         shipped 0.8 behaves as 1.0).  Reproduced as is."""
         p = CropParams()
-        rng = self.rng
-        rnd = rng.random
         if spec.jitter_prob:
             # numpy's stream, the samples' (shifts, gammas) pairs in order: ONE block of uniform doubles, cut as the per-sample
             # `uniform(lo, hi, C)` calls would consume it (lo + (hi - lo) * u, RandomState's own arithmetic) -- same values, one call
-            # instead of two per sample
-            u = self.np_rng.random_sample(2 * sum(s_[0] for s_ in shapes))
-            slo, sd = spec.int_min_shift, spec.int_max_shift - spec.int_min_shift
-            glo, gd = spec.gamma_min, spec.gamma_max - spec.gamma_min
-            o = 0
-            for (C, _, _) in shapes:
-                p.shifts.append(slo + sd * u[o:o + C])
-                p.gammas.append(glo + gd * u[o + C:o + 2 * C])
-                o += 2 * C
+            # instead of two per sample, and the arithmetic on the whole block (the per-sample entries of the lists are views)
+            geo = geo if geo is not None else _Geometry(shapes)
+            C, cum, chan = geo.C, geo.cum, geo.chan
+            u = self.np_rng.random_sample(2 * int(cum[-1]))
+            at = np.repeat(2 * cum[:-1], C) + chan                     # sample i's shifts start at 2 * (channels before it), its gammas C_i later
+            shift = spec.int_min_shift + (spec.int_max_shift - spec.int_min_shift) * u[at]
+            gamma = spec.gamma_min + (spec.gamma_max - spec.gamma_min) * u[at + np.repeat(C, C)]
+            bounds = cum.tolist()
+            p.shifts = [shift[a:b] for a, b in zip(bounds[:-1], bounds[1:])]
+            p.gammas = [gamma[a:b] for a, b in zip(bounds[:-1], bounds[1:])]
+            p.jitter_flat = (shift, gamma)
         else:
             p.shifts = [None] * len(shapes)
             p.gammas = [None] * len(shapes)
+        if type(self.rng) is random.Random and not self.python_draws:
+            return self._draw_native(spec, shapes, p, geo if geo is not None else _Geometry(shapes))
+        rng = self.rng
+        rnd = rng.random
         scale = (spec.crop_min_scale, spec.crop_max_scale)
         gray_p, blur_p, sol_p, flip_p, norm_on, norm_p = spec.gray_prob, spec.blur_prob, spec.solarize_prob, spec.flip_prob, spec.normalize is not None, spec.normalize_prob
         boxes, grays, blurs, sols, flips, normed = p.boxes, p.grays, p.blurs, p.solarize, p.flips, p.normalized
@@ -197,6 +219,43 @@ class DeviceMultiCropPipeline:
             flips.append(bool(flip_p and rnd() < flip_p))
             rnd()  # ToTensorV2(always_apply=True): `random.random() < p or always_apply` still draws
             normed.append(bool(norm_on and rnd() < norm_p))
+        return p
+
+    def _draw_native(self, spec: CropSpec, shapes, p: CropParams, geo: _Geometry) -> CropParams:
+        """The per-sample loop of `_draw` in C (`chadavit_draw_crop_params`, csrc/host_draw.hip): continues `self.rng` from its exported
+        Mersenne-Twister state and writes the state back -- same stream, same values as the Python loop below (held equal in
+        tests/test_augment_cpu.py), ~1 ms instead of ~130 ms per 1 024-image 10-crop batch, and not under the interpreter lock the
+        training thread needs for its launches.  Any other generator object (a subclass that counts draws, say) takes the Python loop."""
+        n = len(shapes)
+        version, mt, gauss = self.rng.getstate()
+        st = np.array(mt, dtype=np.uint32)
+        hw = geo.hw
+        boxes = np.empty((n, 4), dtype=np.int64)
+        gray, blur_k, sol_on, flip, normed = (np.empty(n, dtype=np.int32) for _ in range(5))
+        blur_sigma, sol_value = np.empty(n, dtype=np.float64), np.empty(n, dtype=np.float64)
+        ptr = lambda a: ctypes.c_void_p(a.ctypes.data)
+        dbl = ctypes.c_double
+        rc = _lib.lib().chadavit_draw_crop_params(
+            ptr(st), ctypes.c_int(n), ptr(hw), ctypes.c_int(bool(spec.rrc_enabled)), dbl(spec.crop_min_scale), dbl(spec.crop_max_scale),
+            dbl(spec.ratio[0]), dbl(spec.ratio[1]), dbl(spec.gray_prob), dbl(spec.blur_prob), ctypes.c_int(spec.blur_limit[0]),
+            ctypes.c_int(spec.blur_limit[1]), dbl(spec.sigma_limit[0]), dbl(spec.sigma_limit[1]), dbl(spec.solarize_prob),
+            dbl(spec.solarize_threshold), dbl(spec.flip_prob), ctypes.c_int(spec.normalize is not None), dbl(spec.normalize_prob),
+            ptr(boxes), ptr(gray), ptr(blur_k), ptr(blur_sigma), ptr(sol_on), ptr(sol_value), ptr(flip), ptr(normed))
+        if rc != 0:
+            raise RuntimeError(f"chadavit_draw_crop_params failed with code {rc}")
+        self.rng.setstate((version, tuple(st.tolist()), gauss))
+        C = geo.C
+        if gray.any() and (C[gray != 0] != 3).any():
+            i = int(np.nonzero((gray != 0) & (C != 3))[0][0])
+            raise RuntimeError(f"ToGray fired on a {int(C[i])}-channel sample: albumentations raises TypeError there (3-channel images only)")
+        p.boxes = list(map(tuple, boxes.tolist()))
+        p.grays = (gray != 0).tolist()
+        p.blurs = [None if k < 0 else (k, sg) for k, sg in zip(blur_k.tolist(), blur_sigma.tolist())]
+        p.solarize = [v if on else None for on, v in zip(sol_on.tolist(), sol_value.tolist())]
+        p.flips = (flip != 0).tolist()
+        p.normalized = (normed != 0).tolist()
+        p.arrays = {"boxes": boxes, "gray": gray != 0, "blur_k": blur_k, "blur_sigma": blur_sigma, "sol_on": sol_on != 0,
+                    "sol_value": sol_value, "flip": flip != 0, "normed": normed != 0}
         return p
 
     def __call__(self, images: Sequence[np.ndarray], labels: Optional[Sequence[int]] = None, params: Optional[List[CropParams]] = None,
@@ -248,6 +307,7 @@ class DeviceMultiCropPipeline:
             self._staging_ev[k] = torch.cuda.Event()
             self._staging_ev[k].record(torch.cuda.current_stream(self.device))
         crops, used, pending = [], [], []
+        geo = _Geometry(shapes)
         it = iter(params) if params is not None else None
         nchan = sum(nch)
         for spec in self.specs:
@@ -255,10 +315,10 @@ class DeviceMultiCropPipeline:
             # crops" / "all local crops" as a view of it (channels_strategies.adjacent_view) instead of a torch.cat copy
             buf = torch.empty((spec.num_crops * nchan, 1, spec.crop_size, spec.crop_size), device=self.device, dtype=torch.float32)
             for k in range(spec.num_crops):
-                cp = next(it) if it is not None else self._draw(spec, shapes)
+                cp = next(it) if it is not None else self._draw(spec, shapes, geo)
                 used.append(cp)
                 out = buf[k * nchan:(k + 1) * nchan]
-                prep = self._prepare_crop(spec, cp, shapes, offs)
+                prep = self._prepare_crop(spec, cp, shapes, offs, geo)
                 if defer:
                     pending.append((spec, prep, out))
                     crops.append(out)
@@ -287,33 +347,41 @@ class DeviceMultiCropPipeline:
     def _run_crop(self, spec: CropSpec, cp: CropParams, src, shapes, offs, out=None) -> torch.Tensor:
         return self._launch_crop(spec, self._prepare_crop(spec, cp, shapes, offs), src, out=out)
 
-    def _prepare_crop(self, spec: CropSpec, cp: CropParams, shapes, offs) -> dict:
+    def _prepare_crop(self, spec: CropSpec, cp: CropParams, shapes, offs, geo: Optional[_Geometry] = None) -> dict:
         """Per-channel-image descriptor tables for the two kernels, built with numpy (a Python loop over the ~1500 channel images of
         a 512-image batch, ten crops per batch, was the slowest stage of the whole data path) and uploaded: host work + copies only."""
         n = len(shapes)
-        C = np.fromiter((s_[0] for s_ in shapes), dtype=np.int64, count=n)
-        H = np.fromiter((s_[1] for s_ in shapes), dtype=np.int64, count=n)
-        W = np.fromiter((s_[2] for s_ in shapes), dtype=np.int64, count=n)
+        geo = geo if geo is not None else _Geometry(shapes)
+        C, H, W, chan = geo.C, geo.H, geo.W, geo.chan
         off = np.asarray(offs, dtype=np.int64)
         if n and int((H * W).max()) >= 1 << 30:
             raise RuntimeError("source planes of 2^30 pixels or more are not supported (chadavit_crop_resize addresses a crop window with 32-bit byte offsets)")
-        normed = np.asarray(cp.normalized if cp.normalized else [spec.normalize is not None] * n, dtype=bool)
+        ar = cp.arrays   # (the C draw's outputs: the same values as the lists, already arrays)
         grays = cp.grays if cp.grays else [False] * n
-        has_blur = np.fromiter((b is not None and b[0] > 1 for b in cp.blurs), dtype=bool, count=n)
-        has_sol = np.fromiter((t is not None for t in cp.solarize), dtype=bool, count=n)
+        if ar is not None:
+            normed, has_blur, has_sol = ar["normed"], ar["blur_k"] > 1, ar["sol_on"]
+        else:
+            normed = np.asarray(cp.normalized if cp.normalized else [spec.normalize is not None] * n, dtype=bool)
+            has_blur = np.fromiter((b is not None and b[0] > 1 for b in cp.blurs), dtype=bool, count=n)
+            has_sol = np.fromiter((t is not None for t in cp.solarize), dtype=bool, count=n)
         any_jit = any(s_ is not None for s_ in cp.shifts)
         any_fin = bool(normed.any() or has_blur.any() or has_sol.any())
         rep = lambda a: np.repeat(a, C)                                   # per sample -> per channel image
-        chan = np.concatenate([np.arange(c) for c in C])                  # channel index inside its sample
-        box = np.asarray(cp.boxes, dtype=np.int64).reshape(n, 4)          # (y0, x0, h, w)
+        box = ar["boxes"] if ar is not None else np.asarray(cp.boxes, dtype=np.int64).reshape(n, 4)          # (y0, x0, h, w)
+        flips = ar["flip"].astype(np.int64) if ar is not None else np.asarray(cp.flips, dtype=np.int64)
+        if n and int(box[:, 2:4].min()) <= 0:
+            raise RuntimeError("empty crop window (RandomResizedCrop's fallback rounds to 0 pixels on a plane this small): cv2.resize raises on it too")
         desc = np.stack([rep(off) + chan * rep(H * W), rep(H), rep(W), rep(box[:, 1]), rep(box[:, 0]), rep(box[:, 3]), rep(box[:, 2]),
-                         rep(np.asarray(cp.flips, dtype=np.int64))], axis=1)
+                         rep(flips)], axis=1)
         dev = self.device
         prep = {"grays": grays if any(grays) else None, "C": C, "n": n, "shift": None, "gamma": None, "fin": None}
         prep["d"] = torch.from_numpy(desc).to(dev, non_blocking=True)
         if any_jit:   # gamma = -1 marks the channel images whose sample did not draw the jitter (no clamp for them)
-            shift = np.concatenate([np.zeros(c, np.float32) if s_ is None else np.asarray(s_, np.float32) for c, s_ in zip(C, cp.shifts)])
-            gamma = np.concatenate([np.full(c, -1.0, np.float32) if g_ is None else np.asarray(g_, np.float32) for c, g_ in zip(C, cp.gammas)])
+            if cp.jitter_flat is not None:   # every sample drew it (as _draw does): the two arrays as they are
+                shift, gamma = cp.jitter_flat[0].astype(np.float32), cp.jitter_flat[1].astype(np.float32)
+            else:
+                shift = np.concatenate([np.zeros(c, np.float32) if s_ is None else np.asarray(s_, np.float32) for c, s_ in zip(C, cp.shifts)])
+                gamma = np.concatenate([np.full(c, -1.0, np.float32) if g_ is None else np.asarray(g_, np.float32) for c, g_ in zip(C, cp.gammas)])
             prep["shift"], prep["gamma"] = torch.from_numpy(shift).to(dev, non_blocking=True), torch.from_numpy(gamma).to(dev, non_blocking=True)
         if any_fin:
             fin = np.zeros((int(C.sum()), 12), dtype=np.float32)
@@ -323,8 +391,11 @@ class DeviceMultiCropPipeline:
             if has_blur.any():
                 # gaussian_taps for all blurred samples at once (same arithmetic: float64 exponentials, normalised, rounded to float32)
                 idx = np.nonzero(has_blur)[0]
-                ks = np.fromiter((cp.blurs[i][0] for i in idx), dtype=np.int64, count=len(idx))
-                sg = np.fromiter((cp.blurs[i][1] for i in idx), dtype=np.float64, count=len(idx))
+                if ar is not None:
+                    ks, sg = ar["blur_k"][idx].astype(np.int64), ar["blur_sigma"][idx]
+                else:
+                    ks = np.fromiter((cp.blurs[i][0] for i in idx), dtype=np.int64, count=len(idx))
+                    sg = np.fromiter((cp.blurs[i][1] for i in idx), dtype=np.float64, count=len(idx))
                 if ks.max() > 7:
                     raise RuntimeError("GaussianBlur kernel sizes above 7 are not supported on the device path")
                 t = np.arange(7, dtype=np.float64)[None, :] - (ks[:, None] - 1) / 2.0
@@ -334,7 +405,9 @@ class DeviceMultiCropPipeline:
                 rows[idx, 1:8] = (kk / kk.sum(1, keepdims=True)).astype(np.float32)
                 fin[:, 0:8] = np.repeat(rows, C, axis=0)
             if has_sol.any():
-                fin[:, 8] = rep(np.asarray([np.inf if t is None else t for t in cp.solarize], dtype=np.float32))
+                thr = (np.where(ar["sol_on"], ar["sol_value"], np.inf).astype(np.float32) if ar is not None
+                       else np.asarray([np.inf if t is None else t for t in cp.solarize], dtype=np.float32))
+                fin[:, 8] = rep(thr)
             if normed.any():
                 mean, std, mpv = spec.normalize
                 mean, std = np.asarray(mean, np.float32), np.asarray(std, np.float32)

@@ -389,6 +389,18 @@ int chadavit_gemm_nt_mx8_q(const void* Xq, const void* xs, int lds_x, const void
 int chadavit_crop_resize(const float* src, const long long* desc, const float* shift, const float* gamma, float* out,
                          int n_channel_images, int S, void* stream);
 int chadavit_blur_finish(const float* in, const float* fin, float* out, int n_channel_images, int S, void* stream);
+/* HOST function (no GPU work): the random parameters of one crop of n samples, drawn in the order albumentations 1.3.1's Compose consumes
+ * CPython's `random` stream for the reference's transform list (pretrain_dataloader.py:281-326): crop p + RandomResizedCrop parameters
+ * (10 attempts, central fallback), [gray p], [blur p, kernel size, sigma], [solarize p, threshold], [flip p], ToTensorV2 p, [normalize p]
+ * -- a bracketed draw happens only when its probability is non-zero (norm_on for the last).  mt_state: the generator as
+ * random.Random.getstate()[1] holds it (624 MT19937 words + index), continued in place.  hw: n x (H, W) of the samples' planes.
+ * Outputs per sample: boxes (y0, x0, h, w), gray / flip / normed flags, blur_k (-1 = not fired) + blur_sigma, sol_on + sol_value.
+ * Bit-identical to chadavit_amd/data/device_pipeline.py::_draw on the same state (tests/test_augment_cpu.py). */
+int chadavit_draw_crop_params(unsigned int* mt_state, int n, const long long* hw, int rrc_enabled, double scale_lo, double scale_hi,
+                              double ratio_lo, double ratio_hi, double gray_p, double blur_p, int blur_lo, int blur_hi, double sigma_lo,
+                              double sigma_hi, double sol_p, double sol_threshold, double flip_p, int norm_on, double norm_p,
+                              long long* boxes, int* gray, int* blur_k, double* blur_sigma, int* sol_on, double* sol_value, int* flip,
+                              int* normed);
 
 #ifdef __cplusplus
 }

@@ -130,6 +130,72 @@ def test_rrc_parameter_draws():
             assert 0.24 <= h * w / (H * W) <= 1.0 and 0.7 <= w / h <= 1.4
 
 
+def test_native_draws_continue_the_same_stream_as_the_python_statement():
+    """chadavit_draw_crop_params (csrc/host_draw.hip, a host function of the C-ABI library) draws the per-sample parameters from the
+    exported state of the pipeline's `random.Random` and writes the state back: for every transform mix -- RandomResizedCrop with its
+    10 attempts and the central fallback, plain Resize, even blur sizes moved to the next odd one, a solarize threshold, gray,
+    normalize.prob -- and for degenerate and oblong planes it must hand out exactly the values the Python loop hands out (itself pinned
+    to oracle/augment_ref.py above), leave the generator in exactly the same state, and lead to identical descriptor tables."""
+    from chadavit_amd.data.device_pipeline import CropSpec, DeviceMultiCropPipeline
+    specs = [CropSpec(224, 1, crop_min_scale=0.25, crop_max_scale=1.0, jitter_prob=0.8, blur_prob=1.0, flip_prob=0.5),
+             CropSpec(224, 1, crop_min_scale=0.25, crop_max_scale=1.0, jitter_prob=0.8, blur_prob=0.1, solarize_prob=0.2, flip_prob=0.5, gray_prob=0.2,
+                      normalize=([0.5], [0.2], 255.0), normalize_prob=0.7, int_min_shift=-0.1, gamma_max=1.7),
+             CropSpec(96, 3, crop_min_scale=0.05, crop_max_scale=0.25, jitter_prob=0.8, blur_prob=0.5, flip_prob=0.5),
+             CropSpec(64, 1, rrc_enabled=False, blur_prob=0.5, blur_limit=(2, 6), solarize_prob=0.5, solarize_threshold=0.4),
+             CropSpec(64, 2, crop_min_scale=0.9, crop_max_scale=1.0, ratio=(0.2, 0.3)),     # mostly the central fallback
+             CropSpec(64, 1, crop_min_scale=0.9, crop_max_scale=1.0, ratio=(3.0, 4.0))]     # ... its other branch
+    rs = np.random.RandomState(0)
+    mixed = [(3 if i % 5 else int(rs.randint(1, 11)), int(rs.randint(20, 400)), int(rs.randint(20, 400))) for i in range(300)]
+    mixed += [(3, 1, 1), (3, 2, 5), (3, 1000, 7), (1, 7, 1000)]
+    three = [(3, h, w) for _, h, w in mixed]
+    fallbacks = 0
+    for seed in (0, 1, 12345):
+        a, b = DeviceMultiCropPipeline(specs, "cpu", seed=seed), DeviceMultiCropPipeline(specs, "cpu", seed=seed)
+        b.python_draws = True
+        for sp in specs:
+            shapes = three if sp.gray_prob else mixed
+            offs, tot = [], 0
+            for (C, H, W) in shapes:
+                offs.append(tot); tot += C * H * W
+            for _ in range(sp.num_crops):
+                pa, pb = a._draw(sp, shapes), b._draw(sp, shapes)
+                assert pa.arrays is not None and pb.arrays is None   # (really the two implementations)
+                assert pa.boxes == pb.boxes and pa.grays == pb.grays and pa.blurs == pb.blurs and pa.solarize == pb.solarize
+                assert pa.flips == pb.flips and pa.normalized == pb.normalized
+                assert all(type(x) is type(y) for x, y in zip(pa.boxes[0], pb.boxes[0]))
+                assert a.rng.getstate() == b.rng.getstate()
+                if min(min(bx[2], bx[3]) for bx in pa.boxes) > 0:
+                    ta, tb = a._prepare_crop(sp, pa, shapes, offs), b._prepare_crop(sp, pb, shapes, offs)
+                    for k in ("d", "shift", "gamma", "fin"):
+                        assert (ta[k] is None and tb[k] is None) or np.array_equal(ta[k].numpy(), tb[k].numpy(), equal_nan=True), k
+                if sp.ratio != (3.0 / 4.0, 4.0 / 3.0):
+                    fallbacks += sum(1 for (y0, x0, h, w), (_, H, W) in zip(pa.boxes, shapes) if (h == H or w == W))
+                for (y0, x0, h, w), (_, H, W) in zip(pa.boxes, shapes):
+                    assert 0 <= y0 and y0 + h <= H and 0 <= x0 and x0 + w <= W and h >= 0 and w >= 0
+                    assert (h > 0 and w > 0) or min(H, W) < 4   # (round(1 * 0.3) = 0: albumentations' own fallback on a 1-pixel plane)
+    assert fallbacks > 100
+    # ... and an empty crop window is refused where the tables are built (cv2.resize raises on it in the reference)
+    e = DeviceMultiCropPipeline([specs[4]], "cpu", seed=0)
+    with pytest.raises(RuntimeError, match="empty crop window"):
+        e._prepare_crop(specs[4], e._draw(specs[4], [(3, 1, 1)]), [(3, 1, 1)], [0])
+    # a generator object of any other type (here: one that counts) keeps the Python loop -- its draws stay observable
+    class Counting(random.Random):
+        n = 0
+
+        def random(self):
+            self.n += 1
+            return super().random()
+    c = DeviceMultiCropPipeline([specs[3]], "cpu", seed=3)
+    c.rng = Counting(3)
+    assert c._draw(specs[3], mixed).arrays is None and c.rng.n > 2 * len(mixed)
+    # ToGray on a sample that is not 3-channel raises on either path, as albumentations does
+    for py in (False, True):
+        d = DeviceMultiCropPipeline([CropSpec(32, 1, gray_prob=1.0)], "cpu", seed=0)
+        d.python_draws = py
+        with pytest.raises(RuntimeError, match="ToGray fired"):
+            d._draw(d.specs[0], [(3, 40, 40), (2, 40, 40)])
+
+
 def test_idrcell_reader(tmp_path):
     """IDRCell100k format (custom_datasets.py:153-220): csv of (id, list of per-channel files under images/) -> HWC float32."""
     from PIL import Image
