@@ -397,12 +397,35 @@ def run(forced):
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}   # (state_dict finishes the pending centre update)
     timing = gs.reducer.timing_summary() if forced else None
     return losses, pend, nspans, sd, timing
+def eval_modules():
+    # GradSync on the evaluation modules (no head, no teacher), collectives forced: RegressionModel has no `classifier` attribute at all
+    # (the reference deletes it, src/methods/regression.py) -- attach() must reach its `regressor` through `out_layer`; with the backbone
+    # fine-tuned its spans go through the reducer, the linear layer's two gradients in finish(); averages over ONE rank are identities
+    from chadavit_amd.backbones import vit_channels
+    from chadavit_amd.methods.linear import LinearModel
+    from chadavit_amd.methods.regression import RegressionModel
+    from tests.test_linear_gpu import _cfg as lin_cfg
+    ok = []
+    for cls, ft in ((RegressionModel, True), (RegressionModel, False), (LinearModel, False)):
+        bb = vit_channels("dino", patch_size=16, embed_dim=192, return_all_tokens=False, max_number_channels=10)
+        m = cls(bb, lin_cfg(192, False, 3, False, 1 if cls is RegressionModel else 7, ft, 0.1, 0.0)).to(dev)
+        gs = GradSync().attach(m)
+        lin = m.out_layer if hasattr(m, "out_layer") else m.classifier
+        good = (cls is LinearModel or not hasattr(m, "classifier")) and gs.reducer.active and [id(p) for p in gs._plain] == [id(p) for p in lin.parameters()]
+        good = good and ((m.backbone.grad_ready_hook is not None) == ft)
+        for p in lin.parameters():
+            p.grad = torch.full_like(p, 3.0)
+        gs.begin_backward(); gs.finish(); torch.cuda.synchronize()
+        good = good and all(bool((p.grad == 3.0).all()) for p in lin.parameters()) and gs.reducer.bytes == 4 * sum(p.numel() for p in lin.parameters())
+        ok.append(bool(good))
+    return ok
 la, pa, na, sda, _ = run(False)
 lb, pb, nb, sdb, timing = run(True)
+evals = eval_modules()
 same = all(torch.equal(sda[k], sdb[k]) for k in sda)
 diff = [k for k in sda if not torch.equal(sda[k], sdb[k])][:5]
 print("RESULT " + json.dumps({"losses_plain": la, "losses_rccl": lb, "pending_plain": pa, "pending_rccl": pb, "spans": nb, "state_equal": same,
-                              "diff": diff, "timing": timing, "comm_stream": True}), flush=True)
+                              "diff": diff, "timing": timing, "comm_stream": True, "eval_modules": evals}), flush=True)
 dist.barrier(); dist.destroy_process_group()
 """
 
@@ -430,3 +453,4 @@ def test_rccl_code_path_on_one_gpu():
     assert out["pending_rccl"] == [True, True] and out["pending_plain"] == [False, False]
     assert all(n >= 13 for n in out["spans"]), out["spans"]      # 12 blocks' spans (+ embeddings / final norm) + the head
     assert out["timing"] is not None and out["timing"]["steps"] == 2 and out["timing"]["comm_busy_ms_per_step"] > 0, out["timing"]
+    assert out["eval_modules"] == [True, True, True], out["eval_modules"]   # GradSync.attach on RegressionModel (fine-tune / frozen) and LinearModel
