@@ -720,6 +720,22 @@ def data_path_leg(wl, args, dev, tr, steps=8, n_samples=1536, side=256, workers=
             break
     torch.cuda.synchronize()
     pipe_ips = (n - B) / (time.perf_counter() - t0) if n > B else None
+    # ... and with the planes as 8-bit image files store them (IDRCell100K.read_planes(raw=True)): uploaded as bytes, converted on the GPU
+    pool8 = {c: rs.randint(0, 256, size=(c, side, side)).astype(np.uint8) for c in by_c}
+    ds8 = InMemoryPlanes([pool8[c] for c in nch])
+    torch.cuda.synchronize()
+    n, t0 = 0, None
+    for i, batch in enumerate(DevicePrefetcher(ds8, batches * ((steps + 2 + len(batches) - 1) // len(batches)), DeviceMultiCropPipeline(specs, dev, seed=1),
+                                               depth=2, workers=workers, raw_planes=True)):
+        if i == 1:
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+        if i >= 1:
+            n += B
+        if i == steps:
+            break
+    torch.cuda.synchronize()
+    pipe8_ips = (n - B) / (time.perf_counter() - t0) if n > B else None
+    del batch
     # (b) the training step fed by it (the global crops arrive as two specs: adjacent_view falls back to one torch.cat): with the
     # augmentation kernels beside the step on the prefetcher's side stream (the default), and at the head of the step's own stream
     def fed(kernels_on):
@@ -766,7 +782,9 @@ def data_path_leg(wl, args, dev, tr, steps=8, n_samples=1536, side=256, workers=
     raw_mb = sum(c * side * side * 4 for c in nch[:B]) / B / 1e6
     return {"what": "reader threads -> pinned staging ring -> H2D -> chadavit_crop_resize / chadavit_blur_finish on a side stream (DevicePrefetcher), "
                     "synthetic decoded planes in host memory", "raw_plane_side": side, "raw_MB_per_image": round(raw_mb, 2), "reader_threads": workers,
-            "pipeline_alone_images_per_s": None if pipe_ips is None else round(pipe_ips, 1), "step_fed_by_pipeline_images_per_s": round(step_ips, 1),
+            "pipeline_alone_images_per_s": None if pipe_ips is None else round(pipe_ips, 1),
+            "pipeline_alone_from_uint8_planes_images_per_s": None if pipe8_ips is None else round(pipe8_ips, 1),
+            "step_fed_by_pipeline_images_per_s": round(step_ips, 1),
             "step_fed_with_augmentation_kernels_on_the_steps_own_stream_images_per_s": round(step_ips_main, 1),
             "same_steps_on_one_resident_batch_images_per_s": round(resident_ips, 1), "fed_over_resident": round(step_ips / resident_ips, 4),
             "h2d_GBps_at_that_rate": round(step_ips * raw_mb / 1e3, 2),

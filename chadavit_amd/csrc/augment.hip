@@ -86,7 +86,11 @@ __device__ __forceinline__ void resize_band(Ld ld, Jit jitter, const Taps* cols,
   }
 }
 
-__global__ __launch_bounds__(256) void crop_resize_kernel(const float* __restrict__ src, const long long* __restrict__ desc_,
+// T: the element type of the source planes -- float, or the 8 / 16-bit unsigned integers image files store (IDRCell100k: the reference
+// reader casts them to float32 on the host, custom_datasets.py:181-190; here they travel as stored and become float, exactly, where a
+// value is first touched: while a band is staged, or per tap on the global-tap path).
+template <typename T>
+__global__ __launch_bounds__(256) void crop_resize_kernel(const T* __restrict__ src, const long long* __restrict__ desc_,
                                                           const float* __restrict__ shift, const float* __restrict__ gamma,
                                                           float* __restrict__ out, int S, int quads_per_row, unsigned inv_S, int tile_rows, int band_bytes) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(256) void crop_resize_kernel(const float* __restric
   const int c = blockIdx.y;
   const CropDesc d = *reinterpret_cast<const CropDesc*>(desc_ + 8 * (size_t)c);
   const int cw = (int)d.cw, chh = (int)d.ch, W = (int)d.W;
-  const float* pf = src + d.src_off + d.y0 * d.W + d.x0;
+  const T* pf = src + d.src_off + d.y0 * d.W + d.x0;
   const char* p = reinterpret_cast<const char*>(pf);
   float* o = out + (size_t)c * S * S;
   const bool jit = shift != nullptr && gamma[c] >= 0.f;
@@ -131,9 +135,8 @@ __global__ __launch_bounds__(256) void crop_resize_kernel(const float* __restric
     const int n_quads = quads_per_row * nrows;
     for (int q = threadIdx.x; q < n_quads; q += 256) {
       const int ty = q / quads_per_row, x4 = (q - ty * quads_per_row) * 4;
-      const unsigned ro = rows[ty].off[0] * 4u * (unsigned)W;
-      for (int e = 0; e < 4 && x4 + e < S; ++e)
-        o[(unsigned)(ty * S + x4 + e)] = jitter(*reinterpret_cast<const float*>(p + (ro + cols[x4 + e].off[0])));
+      const unsigned ro = rows[ty].off[0] * (unsigned)W;
+      for (int e = 0; e < 4 && x4 + e < S; ++e) o[(unsigned)(ty * S + x4 + e)] = jitter((float)pf[ro + (cols[x4 + e].off[0] >> 2)]);
     }
     return;
   }
@@ -141,8 +144,8 @@ __global__ __launch_bounds__(256) void crop_resize_kernel(const float* __restric
   const unsigned r0 = rows[0].off[0], n_src = rows[nrows - 1].off[3] - r0 + 1;
   const bool staged = (size_t)n_src * cw * 4 <= (size_t)band_bytes;
   __syncthreads();   // (everyone has read r0 / n_src: the row records may now be rewritten as byte offsets)
-  if (threadIdx.x < nrows) {
-    const unsigned pitch = 4u * (unsigned)(staged ? cw : W), base = staged ? r0 : 0u;
+  if (threadIdx.x < nrows) {   // staged: float rows of crop_w in LDS; not staged: rows of W elements of T in global memory
+    const unsigned pitch = staged ? 4u * (unsigned)cw : (unsigned)sizeof(T) * (unsigned)W, base = staged ? r0 : 0u;
 #pragma unroll
     for (int j = 0; j < 4; ++j) rows[threadIdx.x].off[j] = (rows[threadIdx.x].off[j] - base) * pitch;
   }
@@ -150,13 +153,18 @@ __global__ __launch_bounds__(256) void crop_resize_kernel(const float* __restric
     float* bw = reinterpret_cast<float*>(const_cast<char*>(band));
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (unsigned r = wv; r < n_src; r += 4) {
-      const float* srow = pf + (size_t)(r0 + r) * W;
-      for (int x = lane; x < cw; x += 64) bw[r * cw + x] = srow[x];
+      const T* srow = pf + (size_t)(r0 + r) * W;
+      for (int x = lane; x < cw; x += 64) bw[r * cw + x] = (float)srow[x];
+    }
+  } else if (sizeof(T) != 4) {   // the column records hold float byte offsets: in units of T for the global taps
+    for (int t = threadIdx.x; t < S; t += 256) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) cols[t].off[i] = (cols[t].off[i] >> 2) * (unsigned)sizeof(T);
     }
   }
   __syncthreads();
   if (staged) resize_band([&](unsigned off) { return *reinterpret_cast<const float*>(band + off); }, jitter, cols, rows, o, S, inv_S, nrows);
-  else resize_band([&](unsigned off) { return *reinterpret_cast<const float*>(p + off); }, jitter, cols, rows, o, S, inv_S, nrows);
+  else resize_band([&](unsigned off) { return (float)*reinterpret_cast<const T*>(p + off); }, jitter, cols, rows, o, S, inv_S, nrows);
 }
 
 // ---- blur_finish ----------------------------------------------------------------------------------------------------------------------
@@ -282,11 +290,10 @@ __global__ __launch_bounds__(256) void blur_finish_kernel(const float* __restric
 }
 }  // namespace
 
-extern "C" int chadavit_crop_resize(const float* src, const long long* desc, const float* shift, const float* gamma, float* out,
-                                    int n_channel_images, int S, void* stream) {
-  CHADA_ENTRY();
-  if (!src || !desc || !out || n_channel_images <= 0 || S <= 0 || (shift == nullptr) != (gamma == nullptr)) return 1;
-  if (n_channel_images > 65535 || S > 1024) return 2;   // (2 S tap records of 32 bytes in LDS)
+namespace {
+template <typename T>
+int crop_resize_launch(const T* src, const long long* desc, const float* shift, const float* gamma, float* out, int n_channel_images, int S,
+                       void* stream) {
   const int qpr = (S + 3) / 4;
   // band height: ~12 pixels per thread, so that the column table (rebuilt by every block of an image) is amortised; 32 KB of staged
   // source rows cover the band of any crop that is not scaled down by more than ~2x from a <= 256-pixel-wide window
@@ -296,11 +303,30 @@ extern "C" int chadavit_crop_resize(const float* src, const long long* desc, con
   const unsigned inv_S = (unsigned)(0x100000000ull / (unsigned)(S > 1 ? S : 2)) + 1u;   // q / S = umulhi(q, inv_S) for the q that occur (S = 1: unused)
   const int band_bytes = 32768;
   const int gx = (S + tile_rows - 1) / tile_rows;
-  hipLaunchKernelGGL(crop_resize_kernel, dim3((unsigned)gx, (unsigned)n_channel_images), dim3(256),
+  hipLaunchKernelGGL(crop_resize_kernel<T>, dim3((unsigned)gx, (unsigned)n_channel_images), dim3(256),
                      (size_t)(S + tile_rows) * sizeof(Taps) + band_bytes, reinterpret_cast<hipStream_t>(stream), src, desc, shift, gamma, out, S,
                      qpr, inv_S, tile_rows, band_bytes);
   CHADA_CHECK_LAUNCH();
   return 0;
+}
+}  // namespace
+
+extern "C" int chadavit_crop_resize_src(const void* src, int src_kind, const long long* desc, const float* shift, const float* gamma, float* out,
+                                        int n_channel_images, int S, void* stream) {
+  CHADA_ENTRY();
+  if (!src || !desc || !out || n_channel_images <= 0 || S <= 0 || (shift == nullptr) != (gamma == nullptr)) return 1;
+  if (n_channel_images > 65535 || S > 1024) return 2;   // (S + band-height tap records of 32 bytes and the staged rows in LDS)
+  switch (src_kind) {
+    case 0: return crop_resize_launch(static_cast<const float*>(src), desc, shift, gamma, out, n_channel_images, S, stream);
+    case 1: return crop_resize_launch(static_cast<const unsigned char*>(src), desc, shift, gamma, out, n_channel_images, S, stream);
+    case 2: return crop_resize_launch(static_cast<const unsigned short*>(src), desc, shift, gamma, out, n_channel_images, S, stream);
+    default: return 1;
+  }
+}
+
+extern "C" int chadavit_crop_resize(const float* src, const long long* desc, const float* shift, const float* gamma, float* out,
+                                    int n_channel_images, int S, void* stream) {
+  return chadavit_crop_resize_src(src, 0, desc, shift, gamma, out, n_channel_images, S, stream);
 }
 
 extern "C" int chadavit_blur_finish(const float* in, const float* fin, float* out, int n_channel_images, int S, void* stream) {

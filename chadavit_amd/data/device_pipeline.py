@@ -260,7 +260,9 @@ class DeviceMultiCropPipeline:
 
     def __call__(self, images: Sequence[np.ndarray], labels: Optional[Sequence[int]] = None, params: Optional[List[CropParams]] = None,
                  defer: bool = False):
-        """images: per sample a float32 array (C_i, H_i, W_i) (channel planes; sizes may differ between samples).
+        """images: per sample an array (C_i, H_i, W_i) of channel planes (sizes may differ between samples): float32, or uint8 / uint16 as
+        the files store them (`IDRCell100K.read_planes(i, raw=True)`) -- a batch whose samples all share one of the two integer types is
+        uploaded in it, anything else as float32.
         Returns what `one_channel_collate_fn` returns for the same batch: (crops, labels, list_num_channels) with
         crops[k] (sum C, 1, S_k, S_k) fp32 on the device.
 
@@ -269,32 +271,39 @@ class DeviceMultiCropPipeline:
         read the crops, after that stream waits for this call's copies.  `DevicePrefetcher` uses it to run the augmentation kernels
         at the head of the training step's own stream instead of beside the step on a side stream, where their blocks take CU
         slots away from kernels that are tuned to fill every one of them."""
-        planes = [np.ascontiguousarray(im, dtype=np.float32) for im in images]
+        # planes travel as float32, or -- when every sample of the batch is stored that way -- as the 8 / 16-bit unsigned integers the image
+        # files hold: a quarter / half of the staging copy and of the PCIe traffic, converted on the device (exact, = the reference
+        # reader's `.astype(np.float32)`, custom_datasets.py:190)
+        kinds = {np.asarray(im).dtype for im in images}
+        dt = kinds.pop() if len(kinds) == 1 and next(iter(kinds)) in (np.dtype(np.uint8), np.dtype(np.uint16)) else np.dtype(np.float32)
+        planes = [np.ascontiguousarray(im, dtype=dt) for im in images]
         shapes = [tuple(im.shape) for im in planes]
         nch = [s[0] for s in shapes]
         offs, tot = [], 0
         for (C, H, W) in shapes:
             offs.append(tot)
             tot += C * H * W
+        tdt = {np.dtype(np.float32): torch.float32, np.dtype(np.uint8): torch.uint8, np.dtype(np.uint16): torch.uint16}[dt]
         if self.device.type == "cuda":
             k = self._calls % 3
             self._calls += 1
             if self._staging_ev[k] is not None:
                 self._staging_ev[k].synchronize()   # (three batches ago: long complete)
-            if self._staging[k] is None or self._staging[k].numel() < tot:
-                self._staging[k] = torch.empty(max(tot, 1), dtype=torch.float32).pin_memory()
-            host = self._staging[k][:tot]
+            nbytes = tot * dt.itemsize
+            if self._staging[k] is None or self._staging[k].numel() < nbytes:
+                self._staging[k] = torch.empty(max((nbytes + 15) // 16 * 16, 16), dtype=torch.uint8).pin_memory()   # bytes: any plane type
+            host = self._staging[k][:nbytes].view(tdt)
         else:
-            host = torch.empty(tot, dtype=torch.float32)
+            host = torch.empty(tot, dtype=tdt)
         hn = host.numpy()
-        # the raw planes into the pinned staging buffer: 0.8 MB per 3-channel 256 x 256 image, 0.8 GB per 1024-image batch -- one memcpy
-        # stream from the producer thread was the slowest stage of the path (~100 ms per batch); numpy releases the GIL inside large
+        # the raw planes into the pinned staging buffer: 0.8 MB per 3-channel 256 x 256 float image, 0.8 GB per 1024-image batch -- one
+        # memcpy stream from the producer thread was the slowest stage of the path (~100 ms per batch); numpy releases the GIL inside large
         # copies, so a few helper threads run them side by side
         def put(lo, hi):
             for o, im in zip(offs[lo:hi], planes[lo:hi]):
                 hn[o:o + im.size] = im.reshape(-1)
         n_img = len(planes)
-        if tot >= (1 << 24) and n_img >= 16:
+        if tot * dt.itemsize >= (1 << 26) and n_img >= 16:
             if self._copy_pool is None:
                 from concurrent.futures import ThreadPoolExecutor
                 self._copy_pool = ThreadPoolExecutor(max_workers=8, thread_name_prefix="chadavit-stage")

@@ -48,14 +48,18 @@ class IDRCell100K:
         """Channel count per sample (what the token-balanced sampler needs) without opening any image."""
         return [len(paths) for _, paths in self.file_list]
 
-    def read_planes(self, index: int) -> np.ndarray:
-        """(C, H, W) float32: one plane per channel file, values as stored (custom_datasets.py:181-190)."""
+    def read_planes(self, index: int, raw: bool = False) -> np.ndarray:
+        """(C, H, W) float32: one plane per channel file, values as stored (custom_datasets.py:181-190).
+        raw = True: when every channel file of the sample is 8-bit (or every one 16-bit) unsigned, the planes in THAT type -- the device
+        pipeline uploads them as stored and converts on the GPU (same values as the float32 cast, a quarter / half of the bytes)."""
         from PIL import Image
         _, paths = self.file_list[index]
         planes = [np.array(Image.open(p)) for p in paths]
         for p, a in zip(paths, planes):
             if a.ndim != 2:
                 raise RuntimeError(f"{p}: expected a single-channel image, got shape {a.shape}")
+        if raw and len({a.dtype for a in planes}) == 1 and planes[0].dtype in (np.dtype(np.uint8), np.dtype(np.uint16)):
+            return np.stack(planes, 0)
         return np.stack(planes, 0).astype(np.float32)
 
     def __getitem__(self, index):

@@ -28,7 +28,8 @@ import torch
 
 class DevicePrefetcher:
     def __init__(self, dataset, batch_sampler: Iterable[Sequence[int]], pipeline, depth: int = 2, workers: int = 8,
-                 labels: Optional[Sequence[int]] = None, kernels_on: str = "producer", stream: Optional["torch.cuda.Stream"] = None):
+                 labels: Optional[Sequence[int]] = None, kernels_on: str = "producer", stream: Optional["torch.cuda.Stream"] = None,
+                 raw_planes: bool = False):
         if kernels_on not in ("consumer", "producer"):
             raise ValueError("kernels_on: 'consumer' or 'producer'")
         self.defer = kernels_on == "consumer" and pipeline.device.type == "cuda"
@@ -37,6 +38,9 @@ class DevicePrefetcher:
         self.device = pipeline.device
         # stream: the side stream to produce on (default: a new one at the default priority)
         self.stream = (stream if stream is not None else torch.cuda.Stream(device=self.device)) if self.device.type == "cuda" else None
+        # raw_planes: ask the dataset for the planes in their stored integer type (`read_planes(i, raw=True)`): the pipeline uploads 8 / 16-bit
+        # planes as they are and converts on the GPU -- same crops, a quarter / half of the staging copy and the PCIe traffic
+        self.read = (lambda i: dataset.read_planes(i, raw=True)) if raw_planes else dataset.read_planes
         self.read_s = 0.0      # host seconds spent decoding (sum over batches; the reader threads' wall time per batch)
         self.batches = 0
 
@@ -53,7 +57,7 @@ class DevicePrefetcher:
                     if stop.is_set():
                         break
                     t0 = time.perf_counter()
-                    planes = list(pool.map(self.dataset.read_planes, idx))
+                    planes = list(pool.map(self.read, idx))
                     self.read_s += time.perf_counter() - t0
                     labs = [self.labels[i] for i in idx] if self.labels is not None else None
                     launch = None
@@ -116,5 +120,5 @@ class InMemoryPlanes:
     def num_channels(self) -> List[int]:
         return [int(p.shape[0]) for p in self.planes]
 
-    def read_planes(self, index: int):
-        return self.planes[index]
+    def read_planes(self, index: int, raw: bool = False):
+        return self.planes[index]   # (held as decoded: whatever type they have)

@@ -885,10 +885,17 @@ def gemm_nt_mx8(xq, xs, wq, ws, bias=None, epilogue=EPI_NONE, aux=None, out=None
 
 
 # ---- device augmentation ---------------------------------------------------------------------------------------
+_SRC_KINDS = {torch.float32: 0, torch.uint8: 1, torch.uint16: 2}   # src_kind of chadavit_crop_resize_src
+
+
 def crop_resize(src, desc, S, shift=None, gamma=None, out=None):
-    """src: packed fp32 source planes; desc (n, 8) int64 {offset, H, W, x0, y0, cw, ch, flip}; -> (n, 1, S, S) fp32 crops
+    """src: packed source planes, fp32 or as the image files store them (uint8 / uint16: converted on the device, exactly -- the reference
+    reader's `.astype(np.float32)`); desc (n, 8) int64 {element offset, H, W, x0, y0, cw, ch, flip}; -> (n, 1, S, S) fp32 crops
     (bicubic as cv2.INTER_CUBIC, optional per-channel jitter clamp(gamma (x + shift), 0, 1), optional h-flip)."""
-    _req(src, F32, "src"); _req(desc, I64, "desc")
+    kind = _SRC_KINDS.get(src.dtype)
+    if kind is None:
+        raise RuntimeError(f"crop_resize: source planes must be float32, uint8 or uint16, got {src.dtype}")
+    _req(src, src.dtype, "src"); _req(desc, I64, "desc")
     n = desc.shape[0]
     if desc.dim() != 2 or desc.shape[1] != 8:
         raise RuntimeError("crop_resize: desc must be (n, 8) int64")
@@ -897,8 +904,8 @@ def crop_resize(src, desc, S, shift=None, gamma=None, out=None):
     _req(out, F32, "out")
     if shift is not None:
         _req(shift, F32, "shift"); _req(gamma, F32, "gamma")
-    _chk(lib().chadavit_crop_resize(_ptr(src), _ptr(desc), _ptr(shift), _ptr(gamma), _ptr(out), c_int(n), c_int(S), _stream()),
-         "chadavit_crop_resize")
+    _chk(lib().chadavit_crop_resize_src(_ptr(src), c_int(kind), _ptr(desc), _ptr(shift), _ptr(gamma), _ptr(out), c_int(n), c_int(S), _stream()),
+         "chadavit_crop_resize_src")
     return out
 
 

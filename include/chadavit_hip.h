@@ -388,6 +388,11 @@ int chadavit_gemm_nt_mx8_q(const void* Xq, const void* xs, int lds_x, const void
  *   1 / (std * max_pixel_value)}.  4 <= S <= 1024. */
 int chadavit_crop_resize(const float* src, const long long* desc, const float* shift, const float* gamma, float* out,
                          int n_channel_images, int S, void* stream);
+/* The same with source planes of src_kind 0 = float32, 1 = uint8, 2 = uint16: the integer kinds are what the image files store; the
+ * reference reader casts them to float32 on the host (src/data/custom_datasets.py:181-190), here they are uploaded as stored (4x / 2x
+ * less staging and PCIe traffic) and converted -- exactly -- on the device.  desc offsets are in ELEMENTS of the source type. */
+int chadavit_crop_resize_src(const void* src, int src_kind, const long long* desc, const float* shift, const float* gamma, float* out,
+                             int n_channel_images, int S, void* stream);
 int chadavit_blur_finish(const float* in, const float* fin, float* out, int n_channel_images, int S, void* stream);
 /* HOST function (no GPU work): the random parameters of one crop of n samples, drawn in the order albumentations 1.3.1's Compose consumes
  * CPython's `random` stream for the reference's transform list (pretrain_dataloader.py:281-326): crop p + RandomResizedCrop parameters

@@ -220,6 +220,9 @@ def test_idrcell_reader(tmp_path):
     for i in range(3):
         planes = ds.read_planes(i)
         assert planes.dtype == np.float32 and np.array_equal(planes, truth[i])
+        # raw: the stored type when the sample's files share one (sample 1 is a single 16-bit file), float32 otherwise
+        raw = ds.read_planes(i, raw=True)
+        assert raw.dtype == (np.uint16 if i == 1 else np.float32) and np.array_equal(raw.astype(np.float32), truth[i])
         img, label = ds[i]
         assert label == -1 and img.shape == (20 + i, 24, len(rows[i][1])) and np.array_equal(img.transpose(2, 0, 1), truth[i])
     seen = {}

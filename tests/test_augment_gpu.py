@@ -119,6 +119,34 @@ def test_every_path_of_the_resize_and_blur_kernels_vs_oracle():
         ops.crop_resize(torch.zeros(16, device=dev), torch.tensor([[0, 4, 4, 0, 0, 4, 4, 0]], device=dev), 1028)   # S > 1024
 
 
+def test_integer_source_planes_equal_their_float_cast():
+    """Planes uploaded as the files store them (uint8 / uint16, `IDRCell100K.read_planes(raw=True)`) and converted on the device give
+    bit for bit the crops of the same values cast to float32 on the host (the reference reader's `.astype(np.float32)`,
+    custom_datasets.py:190) -- LDS-staged bands, global-tap bands (large planes) and the size-preserving copy path; a batch that mixes
+    storage types travels as float32."""
+    from chadavit_amd.data.device_pipeline import CropSpec, DeviceMultiCropPipeline
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(11)
+    specs = [CropSpec(224, 1, crop_min_scale=0.25, crop_max_scale=1.0, jitter_prob=0.8, blur_prob=0.5, flip_prob=0.5, int_min_shift=-40, int_max_shift=40),
+             CropSpec(96, 2, crop_min_scale=0.05, crop_max_scale=0.4, blur_prob=0.5, flip_prob=0.5),
+             CropSpec(97, 1, crop_min_scale=0.5, crop_max_scale=1.0),
+             CropSpec(224, 1, rrc_enabled=False, flip_prob=0.5)]
+    for dt, hi in ((np.uint8, 256), (np.uint16, 65536)):
+        imgs = [rs.randint(0, hi, size=s).astype(dt) for s in ((3, 224, 224), (1, 150, 201), (2, 700, 900), (5, 97, 131), (1, 224, 224))]
+        a = DeviceMultiCropPipeline(specs, dev, seed=4)(imgs)[0]
+        b = DeviceMultiCropPipeline(specs, dev, seed=4)([im.astype(np.float32) for im in imgs])[0]
+        assert len(a) == len(b) == 5
+        for x, y in zip(a, b):
+            assert x.dtype == torch.float32 and torch.equal(x, y) and float(x.abs().max()) >= 1.0   # (the jittered crop is clamped to [0, 1])
+    mixed = [rs.randint(0, 256, size=(2, 64, 64)).astype(np.uint8), rs.randint(0, 65536, size=(1, 64, 64)).astype(np.uint16)]
+    a = DeviceMultiCropPipeline(specs[:2], dev, seed=5)(mixed)[0]
+    b = DeviceMultiCropPipeline(specs[:2], dev, seed=5)([im.astype(np.float32) for im in mixed])[0]
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    from chadavit_amd import ops
+    with pytest.raises(RuntimeError, match="float32, uint8 or uint16"):
+        ops.crop_resize(torch.zeros(16, device=dev, dtype=torch.int32), torch.tensor([[0, 4, 4, 0, 0, 4, 4, 0]], device=dev), 4)
+
+
 def test_gray_and_draw_order_on_three_channel_samples():
     """A.ToGray (pretrain_dataloader.py:303-304) on 3-channel samples, between the jitter and the blur; it raises on any other
     channel count when it fires, as albumentations does.  Also pins the number of Python-`random` draws per sample against the
