@@ -789,7 +789,9 @@ def data_path_leg(wl, args, dev, tr, steps=8, n_samples=1536, side=256, workers=
             "same_steps_on_one_resident_batch_images_per_s": round(resident_ips, 1), "fed_over_resident": round(step_ips / resident_ips, 4),
             "h2d_GBps_at_that_rate": round(step_ips * raw_mb / 1e3, 2),
             "decode_images_per_s_per_reader_thread": round(decode_ips, 1), "decode_format": f"3 x {side}x{side} 8-bit PNG per image (PIL)",
-            "reader_threads_needed_for_the_step": int(math.ceil(step_ips / decode_ips))}
+            "reader_threads_needed_for_the_step": int(math.ceil(step_ips / decode_ips)),
+            **({"note": "variable-channel workload: every fed batch has its own channel mix (and cost); the resident figure of this leg is ONE of "
+                        "them, so fed_over_resident compares different mixes here -- read it on the fixed-channel workload"} if "-" in wl["channels"] else {})}
 
 
 def main():
