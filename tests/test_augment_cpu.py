@@ -268,6 +268,21 @@ def test_device_prefetcher_plumbing_without_a_gpu():
     it.close()   # generator exit: the producer is told to stop and joined
     assert threading.active_count() <= n0
 
+    class Stored(InMemoryPlanes):   # a reader with the two modes of IDRCell100K.read_planes: stored type on request, float32 otherwise
+        def read_planes(self, index, raw=False):
+            return self.planes[index] if raw else self.planes[index].astype(np.float32)
+    ds8 = Stored([(rs.rand(c, 4, 5) * 255).astype(np.uint8) for c in (3, 1, 2, 3)])
+    seen = set()
+
+    class TypePipe(FakePipe):
+        def __call__(self, planes, labels=None):
+            seen.update(p.dtype for p in planes)
+            return super().__call__([p.astype(np.float32) for p in planes], labels=labels)
+    for raw, want in ((False, np.float32), (True, np.uint8)):   # raw_planes: the producer asks for the stored type
+        seen.clear()
+        assert len(list(DevicePrefetcher(ds8, [[0, 1], [2, 3]], TypePipe(), depth=1, workers=2, raw_planes=raw))) == 2
+        assert seen == {np.dtype(want)}
+
 
 def test_deferred_kernels_return_the_same_batch_and_a_launch_callable():
     """DeviceMultiCropPipeline(..., defer=True) (DevicePrefetcher(kernels_on="consumer")): the call itself only prepares -- on the CPU
