@@ -1606,14 +1606,16 @@ def test_crop_buffer_modified_between_forward_and_backward_is_detected():
     assert torch.isfinite(m.token_learner.proj.weight.grad).all()
 
 
-@pytest.mark.parametrize("n_small,use_bn", [(0, False), (2, False), (0, True)])
-def test_graphed_train_step_matches_eager(n_small, use_bn):
+@pytest.mark.parametrize("n_small,use_bn,parallel", [(0, False, True), (2, False, True), (0, True, True), (2, False, False), (0, True, False)])
+def test_graphed_train_step_matches_eager(n_small, use_bn, parallel):
     """chadavit_amd.graphed.GraphedTrainStep (the whole training step as one hipGraph, device-resident LR / bias corrections / tau /
     teacher temperature) against Trainer.train_step on the same batches: same kernels in the same order, so the losses, the
     student, the EMA teacher, the centre, Adam's moments and the schedules must come out IDENTICAL -- across the epoch boundary
     where the prototypes unfreeze (a second graph: other parameters are active, their Adam step counters lag) and the teacher
     temperature moves.  Round 4 (advisor): with BatchNorm in the heads the running estimates must come out identical and finite (the
-    capture's warm-up steps once ran the optimiser on unset device scalars and left NaN statistics behind); between replays the
+    capture's warm-up steps once ran the optimiser on unset device scalars and left NaN statistics behind); `parallel`: the step captured
+    with DINO's side streams on (teacher || student forward, local-crop pass || backward, weight-gradient GEMMs || backward: a graph
+    with parallel branches, the default) and on one stream -- identical results either way; between replays the
     8-entry cache of ragged descriptions is churned and the freed device blocks are overwritten (a graph must own the index arrays
     it baked in); the loss tensors of all steps are kept and read at the end (each replay must hand out its own)."""
     from chadavit_amd import ragged
@@ -1637,7 +1639,8 @@ def test_graphed_train_step_matches_eager(n_small, use_bn):
         model.load_state_dict(build_sd(192, 4096, use_bn=use_bn))
         model = model.to(dev)
         tr = Trainer(max_epochs=4, steps_per_epoch=3).attach(model)
-        step = GraphedTrainStep(tr) if mode == "graph" else tr.train_step
+        step = GraphedTrainStep(tr, parallel_streams=parallel) if mode == "graph" else tr.train_step
+        assert mode != "graph" or (model.overlap_streams == parallel and model.backbone.dw_side_stream == parallel)
         kept, junk = [], []
         for i, b in enumerate(batches):
             tr.current_epoch = i // 3
