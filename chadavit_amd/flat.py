@@ -34,6 +34,8 @@ class FlatParams:
             self.shapes[n] = p.shape
             off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
         self.numel = off
+        self._views: Dict[tuple, torch.Tensor] = {}
+        self._home: Optional[List[int]] = None   # where each parameter's storage must point (attached())
         self.flat = torch.zeros(off, device=self.device, dtype=torch.float32)
         self.grad = torch.zeros(off, device=self.device, dtype=torch.float32)
         self.bf16 = torch.zeros(off, device=self.device, dtype=torch.bfloat16)
@@ -126,17 +128,26 @@ class FlatParams:
 
     # ---- views -------------------------------------------------------------------------------
     def view(self, buf: torch.Tensor, name: str) -> torch.Tensor:
-        o = self.offsets[name]
-        shape = self.shapes[name]
-        n = 1
-        for s in shape:
-            n *= s
-        return buf[o:o + n].view(shape)
+        # the slabs live as long as this object and a parameter's place in them never moves: each (slab, name) view is built once (a
+        # training step asks for ~500 of them; slicing + reshaping anew cost ~1.2 ms of interpreter per step in the launch-bound regime)
+        key = (buf.data_ptr(), buf.dtype, name)
+        v = self._views.get(key)
+        if v is None:
+            o = self.offsets[name]
+            shape = self.shapes[name]
+            n = 1
+            for s in shape:
+                n *= s
+            v = self._views[key] = buf[o:o + n].view(shape)
+        return v
 
     def w(self, name: str) -> torch.Tensor:
         """bf16 shadow of a weight, viewed 2-D (rows = out features)."""
-        v = self.view(self.bf16, name)
-        return v.view(v.shape[0], -1)
+        v = self._views.get(("w2d", name))
+        if v is None:
+            v0 = self.view(self.bf16, name)
+            v = self._views[("w2d", name)] = v0.view(v0.shape[0], -1)
+        return v
 
     def wt(self, name: str) -> torch.Tensor:
         return self._t[name]
@@ -195,7 +206,11 @@ class FlatParams:
 
     # ---- freshness of the bf16 shadows ---------------------------------------------------------
     def attached(self) -> bool:
-        return all(p.data_ptr() == self.flat.data_ptr() + 4 * self.offsets[n] for n, p in zip(self.names, self.params))
+        """Do the parameters still live in the slab (nobody re-pointed a `.data`)?  Asked a dozen times per step: one list comparison."""
+        if self._home is None:
+            base = self.flat.data_ptr()
+            self._home = [base + 4 * self.offsets[n] for n in self.names]
+        return [p.data_ptr() for p in self.params] == self._home
 
     def _version(self) -> int:
         return sum(p._version for p in self.params) + self._manual_version
