@@ -33,6 +33,35 @@ def declared_symbols(header: str = HEADER):
     return sorted(declared_prototypes(header))
 
 
+_ARG_TYPES = {"ptr": ctypes.c_void_p, "int": ctypes.c_int, "float": ctypes.c_float, "double": ctypes.c_double, "long long": ctypes.c_longlong}
+
+
+def declared_signatures(header: str = HEADER):
+    """{entry point: [argument kind, ...]} with kind in ptr / int / float / double / long long, parsed from the public header (comments
+    stripped): what `lib()` installs as ctypes `argtypes` -- a call then takes plain Python ints / floats / addresses (no ctypes object per
+    argument: ~1 ms of a 700-launch step) and a mistyped argument is an ArgumentError instead of a silently truncated register."""
+    with open(header) as f:
+        src = f.read()
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", " ", src)
+    out = {}
+    for _, name, args in re.findall(r"\b(int|long long)\s+(chadavit_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+        kinds = []
+        for a in args.split(","):
+            a = " ".join(a.split())
+            if a in ("", "void"):
+                continue
+            if "*" in a:
+                kinds.append("ptr")
+            else:
+                t = a.rsplit(" ", 1)[0].replace("const ", "").strip()
+                if t not in _ARG_TYPES:
+                    raise HipExtensionMissing(f"{header}: {name}: argument type {t!r} is not one the binding knows")
+                kinds.append(t)
+        out[name] = kinds
+    return out
+
+
 _lib = None
 
 
@@ -44,9 +73,11 @@ def lib() -> ctypes.CDLL:
                 f"{LIB_PATH} not found: build it with `python -m chadavit_amd.build` (hipcc, gfx950). "
                 "chadavit_amd has no CPU fallback.")
         _lib = ctypes.CDLL(LIB_PATH)
+        sigs = declared_signatures()
         for name, ret in declared_prototypes().items():
             fn = getattr(_lib, name)  # AttributeError if the library does not export a declared symbol
             fn.restype = ctypes.c_longlong if ret == "long long" else ctypes.c_int  # as the header declares it
+            fn.argtypes = [_ARG_TYPES[k] for k in sigs[name]]
         if _lib.chadavit_abi_version() != ABI_VERSION:
             raise HipExtensionMissing(f"ABI mismatch: library {_lib.chadavit_abi_version()} != binding {ABI_VERSION}; rebuild")
     return _lib

@@ -15,13 +15,15 @@ import torch
 
 from ._lib import lib
 
-c_int, c_float, c_ll, c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_longlong, ctypes.c_void_p
+# The entry points carry ctypes argtypes (chadavit_amd._lib, parsed from the header): arguments go in as plain Python numbers / addresses.
+# The names below survive from the time every argument was wrapped in a ctypes object; they now only normalise the Python type.
+c_int, c_float, c_ll = int, float, int
 
 EPI_NONE, EPI_RELU, EPI_GELU, EPI_RESID, EPI_RELUMASK, EPI_GELUBWD = range(6)
 
 
 def _ptr(t: Optional[torch.Tensor]):
-    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+    return t.data_ptr() if t is not None else None
 
 
 # torch.cuda.current_stream() builds a Stream object through several Python layers (~8 us): at ~200 launches per pass that was a fifth of the
@@ -30,7 +32,7 @@ _raw_stream, _cur_device = torch._C._cuda_getCurrentRawStream, torch._C._cuda_ge
 
 
 def _stream():
-    return c_void_p(_raw_stream(_cur_device()))
+    return _raw_stream(_cur_device())
 
 
 _DEBUG_SYNC = bool(os.environ.get("CHADAVIT_DEBUG_SYNC"))
@@ -525,7 +527,7 @@ def attn_bwd(qkv, out, dout, lse, cu, work, H, dqkv=None, delta=None, side=None)
     main = torch.cuda.current_stream()
     call(1, _stream())
     side.wait_stream(main)
-    call(4, c_void_p(side.cuda_stream))
+    call(4, side.cuda_stream)
     call(2, _stream())
     # every later use / free / reuse of these tensors happens on `main` after this wait -> no record_stream needed
     main.wait_stream(side)
