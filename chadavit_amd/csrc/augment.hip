@@ -49,20 +49,22 @@ __device__ __forceinline__ void cubic_w(float t, float (&w)[4]) {
 // addresses, 1.45 ms; with the tables but the 16 taps still read from global memory, 1.35 ms although the VALU work had dropped 5x -- 16
 // scattered dword loads per pixel are bound by the texture addresser (~16 cycles per wave64 dword load), not by VALU or HBM.  Per pixel
 // the arithmetic -- mapping, weights, order of the 4 x 4 sum -- never changed, and the results are bit-identical across the versions.
-// A band whose source rows do not fit the LDS budget (heavy down-scaling of a large plane) reads its taps from global memory with 32-bit
-// byte offsets from the crop window's corner: a plane must be smaller than 2^30 pixels (host check in device_pipeline.py).
+// The band goes through LDS in sub-bands of as many output rows as fit a small budget (13 KB: occupancy beats band height); only a window so
+// wide that not even one output row's four source rows fit reads its taps from global memory, with 32-bit byte offsets from the crop window's
+// corner: a plane must be smaller than 2^30 pixels (host check in device_pipeline.py).
 struct Taps {
   unsigned off[4];   // columns: byte offsets within a source row; rows: source row indices (relative to the crop window)
   float w[4];
 };
 
-// The band's pixels: v = sum_j wy[j] (sum_i wx[i] src[yy[j]][xx[i]]) with the taps read through `ld` (byte offset -> value: the staged rows
-// in LDS, or global memory).  A thread owns ONE output column and four rows of it: neighbouring lanes read neighbouring source columns
-// (stride crop_w / S words: no LDS bank pile-up, which a thread-per-4-columns mapping has at stride ~4), the column taps are read once per
-// four pixels, the row taps are a broadcast, and a wave's stores are whole lines.  `rows[].off` hold byte offsets here.
+// Pixels of output rows [ty0, ty0 + nrows) of the block's band: v = sum_j wy[j] (sum_i wx[i] src[yy[j]][xx[i]]) with the taps read through
+// `ld` (byte offset -> value: the staged rows in LDS, or global memory); a source row yy sits at byte (yy - base) * pitch.  A thread owns ONE
+// output column and four rows of it: neighbouring lanes read neighbouring source columns (stride crop_w / S words: no LDS bank pile-up, which
+// a thread-per-4-columns mapping has at stride ~4), the column taps are read once per four pixels, the row taps are a broadcast, and a
+// wave's stores are whole lines.
 template <class Ld, class Jit>
 __device__ __forceinline__ void resize_band(Ld ld, Jit jitter, const Taps* cols, const Taps* rows, float* __restrict__ o, int S, unsigned inv_S,
-                                            int nrows) {
+                                            int ty0, int nrows, unsigned base, unsigned pitch) {
   const int n_items = ((nrows + 3) >> 2) * S;
   for (int q = threadIdx.x; q < n_items; q += 256) {
     const int rg = S == 1 ? q : (int)__umulhi((unsigned)q, inv_S), x = q - rg * S;   // q / S (exact: q * S < 2^32)
@@ -71,16 +73,17 @@ __device__ __forceinline__ void resize_band(Ld ld, Jit jitter, const Taps* cols,
     for (int e = 0; e < 4; ++e) {
       const int ty = rg * 4 + e;
       if (ty < nrows) {
-        const Taps ry = rows[ty];
+        const Taps ry = rows[ty0 + ty];
         float v = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+          const unsigned ro = (ry.off[j] - base) * pitch;
           float a = 0.f;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) a += cx.w[i] * ld(ry.off[j] + cx.off[i]);
+          for (int i = 0; i < 4; ++i) a += cx.w[i] * ld(ro + cx.off[i]);
           v += ry.w[j] * a;
         }
-        o[(unsigned)(ty * S + x)] = jitter(v);
+        o[(unsigned)((ty0 + ty) * S + x)] = jitter(v);
       }
     }
   }
@@ -140,31 +143,42 @@ __global__ __launch_bounds__(256) void crop_resize_kernel(const T* __restrict__ 
     }
     return;
   }
-  // the band's source rows (the tables are monotonic: first row's first tap .. last row's last tap), staged when they fit
-  const unsigned r0 = rows[0].off[0], n_src = rows[nrows - 1].off[3] - r0 + 1;
-  const bool staged = (size_t)n_src * cw * 4 <= (size_t)band_bytes;
-  __syncthreads();   // (everyone has read r0 / n_src: the row records may now be rewritten as byte offsets)
-  if (threadIdx.x < nrows) {   // staged: float rows of crop_w in LDS; not staged: rows of W elements of T in global memory
-    const unsigned pitch = staged ? 4u * (unsigned)cw : (unsigned)sizeof(T) * (unsigned)W, base = staged ? r0 : 0u;
+  // The band's source rows go through LDS in SUB-BANDS of as many output rows as fit `band_bytes` (the tables are monotonic: a sub-band
+  // touches source rows first row's first tap .. last row's last tap, at most rows * crop_h / S + 4 of them, crop_w wide).  A small budget
+  // is the point: ~13 KB per block keeps 7 blocks on a CU and the three phases of a sub-band (stage, barrier, taps) short -- 8-row bands in
+  // 13 KB measured 1.84 ms per 1 024-image batch against 2.32 ms for 16-row bands in 32 KB and 4.1 ms for 32 rows in 48 KB.  Only when not even
+  // one output row fits (a window wider than band_bytes / 16) do the taps come from global memory.
+  const int fit_src = band_bytes / (4 * cw);                                             // source rows the budget holds
+  const int sub = fit_src >= 5 ? max(1, min(nrows, (int)((fit_src - 4) / (scy > 1e-9 ? scy : 1e-9)))) : 0;   // (uniform)
+  if (sub == 0) {
+    if (sizeof(T) != 4) {   // the column records hold float byte offsets: in units of T for the global taps
+      __syncthreads();
+      for (int t = threadIdx.x; t < S; t += 256) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) rows[threadIdx.x].off[j] = (rows[threadIdx.x].off[j] - base) * pitch;
+        for (int i = 0; i < 4; ++i) cols[t].off[i] = (cols[t].off[i] >> 2) * (unsigned)sizeof(T);
+      }
+      __syncthreads();
+    }
+    resize_band([&](unsigned off) { return (float)*reinterpret_cast<const T*>(p + off); }, jitter, cols, rows, o, S, inv_S, 0, nrows, 0u,
+                (unsigned)sizeof(T) * (unsigned)W);
+    return;
   }
-  if (staged) {
-    float* bw = reinterpret_cast<float*>(const_cast<char*>(band));
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float* bw = reinterpret_cast<float*>(const_cast<char*>(band));
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int s0 = 0; s0 < nrows; s0 += sub) {
+    const int rs = min(sub, nrows - s0);
+    const unsigned r0 = rows[s0].off[0];
+    unsigned n_src = rows[s0 + rs - 1].off[3] - r0 + 1;
+    if ((size_t)n_src * cw * 4 > (size_t)band_bytes) n_src = (unsigned)fit_src;   // (cannot happen with the bound above; never overrun the buffer)
+    if (s0) __syncthreads();   // the previous sub-band's taps are done with the buffer
     for (unsigned r = wv; r < n_src; r += 4) {
       const T* srow = pf + (size_t)(r0 + r) * W;
       for (int x = lane; x < cw; x += 64) bw[r * cw + x] = (float)srow[x];
     }
-  } else if (sizeof(T) != 4) {   // the column records hold float byte offsets: in units of T for the global taps
-    for (int t = threadIdx.x; t < S; t += 256) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) cols[t].off[i] = (cols[t].off[i] >> 2) * (unsigned)sizeof(T);
-    }
+    __syncthreads();
+    resize_band([&](unsigned off) { return *reinterpret_cast<const float*>(band + off); }, jitter, cols, rows, o, S, inv_S, s0, rs, r0,
+                4u * (unsigned)cw);
   }
-  __syncthreads();
-  if (staged) resize_band([&](unsigned off) { return *reinterpret_cast<const float*>(band + off); }, jitter, cols, rows, o, S, inv_S, nrows);
-  else resize_band([&](unsigned off) { return (float)*reinterpret_cast<const T*>(p + off); }, jitter, cols, rows, o, S, inv_S, nrows);
 }
 
 // ---- blur_finish ----------------------------------------------------------------------------------------------------------------------
@@ -295,13 +309,13 @@ template <typename T>
 int crop_resize_launch(const T* src, const long long* desc, const float* shift, const float* gamma, float* out, int n_channel_images, int S,
                        void* stream) {
   const int qpr = (S + 3) / 4;
-  // band height: ~12 pixels per thread, so that the column table (rebuilt by every block of an image) is amortised; 32 KB of staged
-  // source rows cover the band of any crop that is not scaled down by more than ~2x from a <= 256-pixel-wide window
-  int tile_rows = 768 / qpr;
+  // rows per block: ~6 pixels per thread and sub-band, so that the column table (rebuilt by every block of an image) is amortised; 13 KB of
+  // staged source rows per block (see the kernel: occupancy beats band height)
+  int tile_rows = 384 / qpr;
   tile_rows = tile_rows < 8 ? 8 : (tile_rows + 3) & ~3;
   if (tile_rows > S) tile_rows = S;
   const unsigned inv_S = (unsigned)(0x100000000ull / (unsigned)(S > 1 ? S : 2)) + 1u;   // q / S = umulhi(q, inv_S) for the q that occur (S = 1: unused)
-  const int band_bytes = 32768;
+  const int band_bytes = 13312;
   const int gx = (S + tile_rows - 1) / tile_rows;
   hipLaunchKernelGGL(crop_resize_kernel<T>, dim3((unsigned)gx, (unsigned)n_channel_images), dim3(256),
                      (size_t)(S + tile_rows) * sizeof(Taps) + band_bytes, reinterpret_cast<hipStream_t>(stream), src, desc, shift, gamma, out, S,
