@@ -16,7 +16,11 @@ import torch
 
 
 class Trainer:
-    def __init__(self, max_epochs: int, steps_per_epoch: int, grad_sync=None):
+    def __init__(self, max_epochs: int, steps_per_epoch: int, grad_sync=None, graph: bool = False):
+        """graph = True: `train_step` replays the whole step as one hipGraph per batch signature (chadavit_amd.graphed.GraphedTrainStep:
+        the launch-bound small-batch regime, fixed-channel data, single process, fused AdamW) -- same results as the eager step."""
+        self.graph = bool(graph)
+        self._graphed = None
         self.max_epochs = max_epochs
         self.steps_per_epoch = steps_per_epoch
         self.estimated_stepping_batches = max_epochs * steps_per_epoch
@@ -47,6 +51,20 @@ class Trainer:
         return fn(*args) if callable(fn) else None
 
     def train_step(self, batch, batch_idx: int = 0) -> torch.Tensor:
+        if self.graph:
+            if self._graphed is None:
+                from .graphed import GraphedTrainStep
+                self._graphed = GraphedTrainStep(self)
+            return self._graphed(batch, batch_idx)
+        return self.eager_step(batch, batch_idx)
+
+    def close_graph(self):
+        """Back to eager steps (step counters written back to the optimiser, the eager loop's stream setting restored)."""
+        if self._graphed is not None:
+            self._graphed.close()
+        self.graph, self._graphed = False, None
+
+    def eager_step(self, batch, batch_idx: int = 0) -> torch.Tensor:
         m = self.model
         m.current_epoch = self.current_epoch
         if batch_idx == 0:

@@ -1638,9 +1638,14 @@ def test_graphed_train_step_matches_eager(n_small, use_bn, parallel):
         model = DINO(cfg)
         model.load_state_dict(build_sd(192, 4096, use_bn=use_bn))
         model = model.to(dev)
-        tr = Trainer(max_epochs=4, steps_per_epoch=3).attach(model)
-        step = GraphedTrainStep(tr, parallel_streams=parallel) if mode == "graph" else tr.train_step
-        assert mode != "graph" or (model.overlap_streams == parallel and model.backbone.dw_side_stream == parallel)
+        # (the default capture through the trainer's own switch in one case: Trainer(graph=True).train_step IS the replay)
+        via_trainer = mode == "graph" and parallel and n_small == 0 and not use_bn
+        tr = Trainer(max_epochs=4, steps_per_epoch=3, graph=via_trainer).attach(model)
+        if via_trainer:
+            step = tr.train_step
+        else:
+            step = GraphedTrainStep(tr, parallel_streams=parallel) if mode == "graph" else tr.train_step
+            assert mode != "graph" or (model.overlap_streams == parallel and model.backbone.dw_side_stream == parallel)
         kept, junk = [], []
         for i, b in enumerate(batches):
             tr.current_epoch = i // 3
@@ -1655,8 +1660,10 @@ def test_graphed_train_step_matches_eager(n_small, use_bn, parallel):
         losses = [float(t.item()) for t in kept]
         del junk
         if mode == "graph":
-            assert len(step.graphs) == 4   # (two channel mixes) x (frozen / unfrozen prototypes)
-            step.close()
+            gts = tr._graphed if via_trainer else step
+            assert len(gts.graphs) == 4   # (two channel mixes) x (frozen / unfrozen prototypes)
+            tr.close_graph() if via_trainer else step.close()
+            assert not tr.graph
         torch.cuda.synchronize()
         opt = tr.optimizer
         with torch.no_grad():   # an eager pass after the last replay reads the weights that replay produced (not one-step-stale shadows)
