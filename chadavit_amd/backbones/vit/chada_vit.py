@@ -602,6 +602,9 @@ class _BackboneFn(torch.autograd.Function):
         rb: RaggedBatch = ctx.rb
         if not ctx.need_grad:
             return (None,) * (7 + ctx.n_params)
+        if ctx.saved_blocks is None:
+            raise RuntimeError("second backward through the same ChAdaViT pass: its saved activations were released by the first one "
+                               "(retain_graph is not supported; run the forward again)")
         flat = m.flat_params()
         dev = dout.device
         D = m.embed_dim
@@ -690,6 +693,10 @@ class _BackboneFn(torch.autograd.Function):
         flat.publish_grads()
         if hook is not None:
             hook(flat, *flat.span(["cls_token", "token_learner.proj.bias"]))
+        # what autograd does with saved tensors after a backward without retain_graph: let go of them.  A loss tensor that is kept around
+        # (a list of per-step losses) would otherwise keep this pass's crop buffer, index arrays and final activations alive through its
+        # graph -- 1-2 GB per step at the bench's batch (found by scratch/r4/fed_soak.py)
+        ctx.patches = ctx.final = ctx.saved_blocks = ctx.rb = None
         return (None, None, None, dpos_patch, None, None, None) + (None,) * ctx.n_params
 
 

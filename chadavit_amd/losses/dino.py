@@ -26,7 +26,10 @@ class _DinoLossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gloss, _gcolsum):
-        return ctx.dstudent.float() * gloss, None, None, None, None
+        d, ctx.dstudent = ctx.dstudent, None   # (released with the backward, as autograd releases saved tensors)
+        if d is None:
+            raise RuntimeError("second backward through the same DINO loss (retain_graph is not supported)")
+        return d.float() * gloss, None, None, None, None
 
 
 class DINOLoss(nn.Module):

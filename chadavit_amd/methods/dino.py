@@ -195,6 +195,8 @@ class _HeadFn(torch.autograd.Function):
         if not ctx.need_grad:
             return (None,) * (3 + ctx.n_params)
         flat = head.flat_params()
+        if ctx.saved is None:
+            raise RuntimeError("second backward through the same DINOHead pass (retain_graph is not supported)")
         xb, pre1, h1, pre2, h2, t, tn, tinv, wt, winv = ctx.saved
         dev = dlogits.device
         G = flat.g
@@ -247,6 +249,7 @@ class _HeadFn(torch.autograd.Function):
             head._pending_backwards = pending - 1
         elif head.grad_ready_hook is not None:
             head.grad_ready_hook(flat, 0, flat.numel)
+        ctx.saved = ctx.bn_saved = None   # (released with the backward, as autograd releases saved tensors)
         return (None, dx, None) + (None,) * ctx.n_params
 
 

@@ -1606,6 +1606,30 @@ def test_crop_buffer_modified_between_forward_and_backward_is_detected():
     assert torch.isfinite(m.token_learner.proj.weight.grad).all()
 
 
+def test_a_kept_loss_does_not_keep_the_batch_alive():
+    """autograd lets go of saved tensors when a backward without retain_graph is done; the custom passes (backbone, head, loss) keep theirs
+    on `ctx` and must do the same -- a training loop that keeps its loss tensors (a list of per-step losses) once kept every step's crop
+    buffer, index arrays and final activations alive through the losses' graphs (1-2 GB per step at the bench's batch; found by
+    scratch/r4/fed_soak.py).  A second backward through a released pass fails loudly."""
+    from chadavit_amd.data.channels_strategies import one_channel_collate_fn
+    from chadavit_amd.methods.dino import DINO
+    from chadavit_amd.trainer import Trainer
+    dev = _dev()
+    model = DINO(_cfg(192, 4096, 2, 2)).to(dev)
+    tr = Trainer(max_epochs=4, steps_per_epoch=100).attach(model)
+    kept, mem = [], []
+    for i in range(8):
+        crops, labels, ncl = one_channel_collate_fn(P.make_images([3] * 16, [224, 224, 96, 96], seed=900 + i))
+        kept.append(tr.train_step(([c.to(dev) for c in crops], labels.to(dev), ncl), i))
+        torch.cuda.synchronize()
+        mem.append(torch.cuda.memory_allocated())
+    assert all(torch.isfinite(l) for l in kept)
+    per_step_inputs = 16 * 3 * (2 * 224 * 224 + 2 * 96 * 96) * 4
+    assert mem[-1] - mem[3] < per_step_inputs // 2, (mem, per_step_inputs)   # four more kept losses: nowhere near four batches
+    with pytest.raises(RuntimeError, match="second backward"):
+        kept[-1].backward()
+
+
 @pytest.mark.parametrize("n_small,use_bn,parallel", [(0, False, True), (2, False, True), (0, True, True), (2, False, False), (0, True, False)])
 def test_graphed_train_step_matches_eager(n_small, use_bn, parallel):
     """chadavit_amd.graphed.GraphedTrainStep (the whole training step as one hipGraph, device-resident LR / bias corrections / tau /
