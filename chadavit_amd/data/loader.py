@@ -26,6 +26,27 @@ from typing import Iterable, Iterator, List, Optional, Sequence
 import torch
 
 
+_ALLOCATOR_TUNED = False
+
+
+def tune_allocator_for_ragged_batches(divisions: int = 8) -> bool:
+    """Variable-channel data gives every batch its own tensor sizes (token rows, channel images): torch's caching allocator then keeps a
+    cached block for every size it has met and asks the driver for a new one whenever none fits -- reserved memory grew 147 -> 206 GiB over 150
+    steps of the cfg2-mixed workload at 256 images (hipMalloc stalls: 2 040 images/s) and expandable segments are not supported on this
+    platform.  `roundup_power2_divisions` makes the allocator round request sizes to 1/`divisions` of a power of two, so blocks are reused
+    across batches: 118.6 GiB reached after 50 steps and flat from there, 2 290 images/s (scratch/r4/fed_soak.py --mixed).  Applied once per
+    process; `DevicePrefetcher` calls it when its dataset reports more than one channel count.  Returns whether the setting was applied."""
+    global _ALLOCATOR_TUNED
+    if _ALLOCATOR_TUNED or not torch.cuda.is_available():
+        return False
+    try:
+        torch.cuda.memory._set_allocator_settings(f"roundup_power2_divisions:{int(divisions)}")
+    except Exception:  # noqa: BLE001 -- an allocator back end without the option: nothing to tune
+        return False
+    _ALLOCATOR_TUNED = True
+    return True
+
+
 class DevicePrefetcher:
     def __init__(self, dataset, batch_sampler: Iterable[Sequence[int]], pipeline, depth: int = 2, workers: int = 8,
                  labels: Optional[Sequence[int]] = None, kernels_on: str = "producer", stream: Optional["torch.cuda.Stream"] = None,
@@ -41,6 +62,12 @@ class DevicePrefetcher:
         # raw_planes: ask the dataset for the planes in their stored integer type (`read_planes(i, raw=True)`): the pipeline uploads 8 / 16-bit
         # planes as they are and converts on the GPU -- same crops, a quarter / half of the staging copy and the PCIe traffic
         self.read = (lambda i: dataset.read_planes(i, raw=True)) if raw_planes else dataset.read_planes
+        if self.device.type == "cuda" and callable(getattr(dataset, "num_channels", None)):
+            try:
+                if len(set(dataset.num_channels())) > 1:
+                    tune_allocator_for_ragged_batches()
+            except Exception:  # noqa: BLE001 -- a dataset that cannot tell its channel counts cheaply: leave the allocator alone
+                pass
         self.read_s = 0.0      # host seconds spent decoding (sum over batches; the reader threads' wall time per batch)
         self.batches = 0
 
