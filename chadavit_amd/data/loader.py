@@ -40,7 +40,8 @@ def tune_allocator_for_ragged_batches(divisions: int = 8) -> bool:
     if _ALLOCATOR_TUNED or not torch.cuda.is_available():
         return False
     try:
-        torch.cuda.memory._set_allocator_settings(f"roundup_power2_divisions:{int(divisions)}")
+        setter = getattr(torch._C, "_accelerator_setAllocatorSettings", None) or torch.cuda.memory._set_allocator_settings
+        setter(f"roundup_power2_divisions:{int(divisions)}")
     except Exception:  # noqa: BLE001 -- an allocator back end without the option: nothing to tune
         return False
     _ALLOCATOR_TUNED = True

@@ -34,7 +34,7 @@ for kind in ("float32", "uint8"):
         if (i + 1) % 50 == 0:
             torch.cuda.synchronize()
             mem.append(torch.cuda.memory_reserved() / 2**30)
-            print(f"{kind}: step {i + 1}: {50 * B / (time.perf_counter() - t0):7.1f} images/s  loss {float(losses[-1]):.4f}  reserved {mem[-1]:.1f} GiB", flush=True)
+            print(f"{kind}: step {i + 1}: {50 * B / (time.perf_counter() - t0):7.1f} images/s  loss {float(losses[-1]):.4f}  reserved {mem[-1]:.1f} GiB  peak allocated {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", flush=True)
             t0 = time.perf_counter()
     vals = torch.stack([l.detach() for l in losses]).float()
     assert bool(torch.isfinite(vals).all()), "non-finite loss"
