@@ -375,17 +375,24 @@ __global__ __launch_bounds__(64 * NW, (CB > 1 ? 1 : (DH <= 96 ? (KV32_AT_DH96 ? 
 #pragma unroll
   for (int cb = 0; cb < CB; ++cb) {
     const float inv = 1.0f / lt[cb];
-    if (qrow[cb] < len) {
-      // accumulator register r of block db = O[query][d = db*32 + 8 (r >> 2) + 4 hi + (r & 3)]: four consecutive d per quad
-      bf16_t* orow = out + (size_t)(seq0 + qrow[cb]) * D + h * DH + 4 * hi;
+    // accumulator register r of block db = O[query][d = db*32 + 8 (r >> 2) + 4 hi + (r & 3)]: four consecutive d per quad, the other four
+    // of the same eight in the lane 32 away.  Stored 8 bytes per lane an instruction writes 32 rows x 16 bytes, and the store ISSUE is
+    // what a block's end costs (attention.hip, widen_pair): two quads are packed to bf16 and the halves exchanged, so that the lower
+    // half holds all eight elements of quad q4 and the upper half those of quad q4 + 1 -- 16 bytes per lane, 32 rows x 32 bytes per
+    // instruction, half as many instructions.  (The exchange runs in every lane; only the stores are predicated.)
+    bf16_t* orow = out + (size_t)(seq0 + min(qrow[cb], len - 1)) * D + h * DH + 8 * hi;
 #pragma unroll
-      for (int db = 0; db < DB; ++db)
+    for (int db = 0; db < DB; ++db)
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4)
-          *reinterpret_cast<bf16x4*>(orow + db * 32 + 8 * q4) =
-              pack4(o[cb][db][4 * q4] * inv, o[cb][db][4 * q4 + 1] * inv, o[cb][db][4 * q4 + 2] * inv, o[cb][db][4 * q4 + 3] * inv);
-      if (hi == 0) lse[(size_t)h * T + seq0 + qrow[cb]] = (m[cb] + log2f(lt[cb])) * LN2;
-    }
+      for (int q4 = 0; q4 < 4; q4 += 2) {
+        const u32x2 pa = __builtin_bit_cast(u32x2, pack4(o[cb][db][4 * q4] * inv, o[cb][db][4 * q4 + 1] * inv, o[cb][db][4 * q4 + 2] * inv, o[cb][db][4 * q4 + 3] * inv));
+        const u32x2 pb = __builtin_bit_cast(u32x2, pack4(o[cb][db][4 * q4 + 4] * inv, o[cb][db][4 * q4 + 5] * inv, o[cb][db][4 * q4 + 6] * inv, o[cb][db][4 * q4 + 7] * inv));
+        unsigned a0 = pa[0], a1 = pa[1], b0 = pb[0], b1 = pb[1];
+        swap32x(a0, b0);
+        swap32x(a1, b1);
+        if (qrow[cb] < len) *reinterpret_cast<u32x4*>(orow + db * 32 + 8 * q4) = u32x4{a0, a1, b0, b1};
+      }
+    if (hi == 0 && qrow[cb] < len) lse[(size_t)h * T + seq0 + qrow[cb]] = (m[cb] + log2f(lt[cb])) * LN2;
   }
 }
 

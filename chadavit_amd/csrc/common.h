@@ -107,6 +107,14 @@ __device__ __forceinline__ void swap32(float v, float& a, float& b) {
   b = v;
   asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
 }
+// The same exchanges on two DIFFERENT registers (epilogue store widening): afterwards a = (a.row0, b.row0, a.row2, b.row2) and
+// b = (a.row1, b.row1, a.row3, b.row3) for the 16-lane rows (swap16x), a = (a.lo, b.lo), b = (a.hi, b.hi) for the halves (swap32x).
+__device__ __forceinline__ void swap16x(unsigned& a, unsigned& b) {
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void swap32x(unsigned& a, unsigned& b) {
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
 // reductions over the 4 lanes {l, l^16, l^32, l^48} (same l & 15)
 __device__ __forceinline__ float rows_sum(float v) {
   float a, b;
