@@ -503,7 +503,8 @@ def build_workload(wl, args, rank, world, dev):
     batch = (crops if len(crops) > 1 else crops[0], labels, [list(nch) for _ in sizes])
 
     steps_per_epoch = 1000
-    gs = GradSync() if world > 1 else None
+    from chadavit_amd.parallel import force_collectives
+    gs = GradSync() if (world > 1 or force_collectives()) else None   # (forced: the RCCL code path in a group of ONE rank, rccl_world1_leg)
     tr = Trainer(max_epochs=100, steps_per_epoch=steps_per_epoch, grad_sync=gs).attach(model)
     return model, tr, gs, batch, nch, tokens_per_rank
 
@@ -678,6 +679,37 @@ def other_workload_leg(name, args, dev, steps=3, warmup=2, graph=False, batch=No
     return res
 
 
+def rccl_world1_leg(reference_ms_per_step, batch=512, steps=4, warmup=2):
+    """What the MECHANISM of the data-parallel step costs before any wire is involved: the cfg2 step with every
+    collective of the N > 1 path issued in a process group of ONE RCCL rank (CHADAVIT_FORCE_COLLECTIVES=1: 15 gradient-span hand-overs to
+    the communication stream per step, ReduceOp.AVG, record_stream, the centre's column-sum all-reduce, the exposed-time events), in a
+    CHILD process -- the process group has to be initialised before anything else touches the GPU there -- against the same step without
+    collectives at the same batch (`reference_ms_per_step`, the cfg2-512 leg of this run).  The N = 1 -> N = 2 delta of a later multi-GPU
+    run then splits into this mechanism cost and the wire."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, CHADAVIT_FORCE_COLLECTIVES="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.pop("CHADAVIT_DIST_BACKEND", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "cfg2", "--batch", str(batch), "--steps", str(steps), "--warmup", str(warmup),
+           "--no-other-workloads", "--no-cpu-baseline", "--data", "resident", "--no-full-width-leg", "--no-launch-profile"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or len(lines) != 1:
+        return {"error": f"child rc {r.returncode}: {r.stderr[-400:]}"}
+    c = json.loads(lines[0])
+    rc = c.get("rccl", {})
+    return {"what": "cfg2 step with all data-parallel collectives issued in a process group of ONE rank (child process)",
+            "backend": rc.get("backend"), "world": rc.get("world"), "spans": rc.get("spans"), "bytes_per_step": rc.get("bytes_per_step"),
+            "images_per_gpu": batch, "images_per_s": c["value"], "ms_per_step": c["ms_per_step"],
+            "ms_per_step_without_collectives": reference_ms_per_step,
+            "mechanism_ms_per_step": None if reference_ms_per_step is None else round(c["ms_per_step"] - reference_ms_per_step, 3),
+            "exposed_ms_per_step": rc.get("exposed_ms_per_step"), "comm_busy_ms_per_step_per_rank": rc.get("comm_busy_ms_per_step_per_rank")}
+
+
 def data_path_leg(wl, args, dev, tr, steps=8, n_samples=1536, side=256, workers=32):
     """SURVEY 8(f)2 throughput: can the device data path feed the step?  Synthetic raw planes (C x side x side float32, the channel
     mix of the workload) held in host memory stand for decoded images; the decode itself is timed separately on a small on-disk
@@ -705,7 +737,7 @@ def data_path_leg(wl, args, dev, tr, steps=8, n_samples=1536, side=256, workers=
 
     def loader(kernels_on="producer"):
         return DevicePrefetcher(ds, batches * ((steps + 2 + len(batches) - 1) // len(batches)), DeviceMultiCropPipeline(specs, dev, seed=1), depth=2,
-                                workers=workers, kernels_on=kernels_on)
+                                workers=workers, kernels_on=kernels_on, tune_allocator=len(set(nch)) > 1)
 
     # (a) pipeline alone
     torch.cuda.synchronize()
@@ -835,7 +867,11 @@ def main():
     barrier()
     t0 = time.perf_counter()
     last = None
+    fault = os.environ.get("CHADAVIT_BENCH_FAULT")   # "rank:step" -- test hook: that rank dies (SIGKILL) in front of that timed step
     for i in range(args.steps):
+        if fault and fault == f"{rank}:{i}":
+            import signal
+            os.kill(os.getpid(), signal.SIGKILL)
         last = tr.train_step(batch, args.warmup + i)
     torch.cuda.synchronize()
     dt_local = time.perf_counter() - t0   # this rank's own time to finish its K steps (before waiting for the others)
@@ -843,7 +879,7 @@ def main():
     dt = time.perf_counter() - t0
     comm_timing = None
     rank_ms = None
-    if world > 1:
+    if gs is not None:   # (world > 1, or the collectives forced in a group of one rank)
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -953,7 +989,7 @@ def main():
         # the data-path collectives of one step: gradient spans averaged on the communication stream while the
         # backward continues, + the P-float centre column sum
         red = gs.reducer if gs is not None else None
-        out["rccl"] = {"backend": dist.get_backend() if world > 1 else None, "world": world,
+        out["rccl"] = {"backend": dist.get_backend() if dist.is_initialized() else None, "world": world,
                        "spans": len(red.spans) if red is not None else 0,
                        "bytes_per_step": (red.bytes if red is not None else 0) + (4 * wl["P"] if world > 1 else 0),
                        "grad_op": "all_reduce(AVG) per block span on a side stream, overlapped with backward" if world > 1 else None,
@@ -985,13 +1021,21 @@ def main():
             torch.cuda.empty_cache()
             legs = {}
             # ("cfg2-512": the headline workload at rounds 2b-3's 512 images per GPU, for like-for-like comparison with their records)
-            for name, kw in (("cfg3", {}), ("cfg5", {}), ("cfg1", {"steps": 30, "warmup": 3}), ("cfg1-graph", {"steps": 30, "warmup": 3, "graph": True}),
+            # ("cfg2-mixed": the north star's literal target -- Tiny/16 on 1-10-channel multi-crop batches, U{1..10} channels per image as
+            # HOW_TO_USE.ipynb cell 16 draws them -- since round 5; the eager cfg1 leg made room for it, the graphed one stays)
+            for name, kw in (("cfg2-mixed", {"steps": 4, "warmup": 2, "wl_name": "cfg2-mixed"}), ("cfg3", {}), ("cfg5", {}),
+                             ("cfg1-graph", {"steps": 30, "warmup": 3, "graph": True}),
                              ("cfg2-512", {"steps": 6, "warmup": 2, "batch": 512}), ("cfg2-standard", {"steps": 4, "warmup": 2, "wl_name": "cfg2-standard"})):
                 try:
                     legs[name] = other_workload_leg(kw.pop("wl_name", name.split("-")[0]), args, dev, **kw)
                 except Exception as e:  # noqa: BLE001 - the headline number must still be reported
                     legs[name] = {"error": repr(e)}
             out["config"]["other_workloads"] = legs
+            try:   # (after the legs: this process holds no model any more, the child has the GPU's memory to itself)
+                ref512 = legs.get("cfg2-512", {}).get("ms_per_step")
+                out["rccl"]["world1_mechanism"] = rccl_world1_leg(ref512)
+            except Exception as e:  # noqa: BLE001
+                out["rccl"]["world1_mechanism"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             threads = min(os.cpu_count() or 1, 128)
             try:
@@ -999,7 +1043,7 @@ def main():
             except Exception as e:  # noqa: BLE001 - the GPU number must still be reported
                 out["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": threads, "kind": "port", "sample": f"failed: {e!r}"}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():   # (world > 1, or a forced group of one rank)
         dist.barrier()
         dist.destroy_process_group()
 

@@ -12,10 +12,26 @@ import torch  # noqa: F401  -- MUST precede the CDLL below: both link libamdhip6
 #                              one already mapped, otherwise the process ends up with two HIP runtimes (hipErrorNoDevice)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-# CHADAVIT_HIP_LIB: load another build of the same ABI instead (same-box A/B of kernel variants; see scratch/)
-LIB_PATH = os.environ.get("CHADAVIT_HIP_LIB") or os.path.join(HERE, "libchadavit_hip.so")
+PRODUCT_LIB = os.path.join(HERE, "libchadavit_hip.so")
+
+
+def _resolve_lib_path() -> str:
+    """CHADAVIT_HIP_LIB loads another build of the same ABI instead of the product library (same-box A/B of kernel variants: the side
+    builds under scratch/sidebuild/).  Such a library is foreign code with the product's name on its results, so the variable alone is
+    not enough: it is honoured only together with CHADAVIT_ALLOW_FOREIGN_LIB=1, and refused loudly otherwise."""
+    other = os.environ.get("CHADAVIT_HIP_LIB")
+    if not other or os.path.realpath(other) == os.path.realpath(PRODUCT_LIB):
+        return PRODUCT_LIB
+    if os.environ.get("CHADAVIT_ALLOW_FOREIGN_LIB") != "1":
+        raise HipExtensionMissing(
+            f"CHADAVIT_HIP_LIB={other!r} names a library other than the product's ({PRODUCT_LIB}); set CHADAVIT_ALLOW_FOREIGN_LIB=1 to load it "
+            "(A/B measurement runs only) or unset the variable")
+    return other
+
+
+LIB_PATH = None  # resolved at the first lib() call
 HEADER = os.path.join(os.path.dirname(HERE), "include", "chadavit_hip.h")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class HipExtensionMissing(RuntimeError):
@@ -66,8 +82,9 @@ _lib = None
 
 
 def lib() -> ctypes.CDLL:
-    global _lib
+    global _lib, LIB_PATH
     if _lib is None:
+        LIB_PATH = _resolve_lib_path()
         if not os.path.exists(LIB_PATH):
             raise HipExtensionMissing(
                 f"{LIB_PATH} not found: build it with `python -m chadavit_amd.build` (hipcc, gfx950). "

@@ -15,7 +15,7 @@ from __future__ import annotations
 import math
 import os
 from functools import partial
-from typing import List, Optional, Sequence
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 import torch.nn as nn
@@ -104,6 +104,11 @@ class ChAdaViT(nn.Module):
         # > 1: that many backward passes of this step accumulate into the gradient slab (DINO's standard_multicrop_loss option: the
         # global-crop and the local-crop pass); the spans are final -- and the hook fires -- during the LAST of them
         self._pending_backwards = 0
+        # gradient-span hand-over vs the part of pos_embed's gradient that travels through autograd (bicubic-resized position rows): see
+        # _expect_pos_accumulation
+        self._pos_autograd_pending = False
+        self._pos_span_deferred = None
+        self._pos_hook_handle = None
         # weight-gradient GEMMs on a second HIP stream beside the dX chain.  Default by measurement (round 2, same box, img/s
         # overlapped vs one stream): Base 150.4 vs 145.4 -- its GEMM-chain kernels leave grid tails the side stream fills;
         # Tiny 4469 vs 4540, Small 1087 vs 1084, the 4-image reference config 386 vs 428 -- the fused block kernels fill the
@@ -132,6 +137,9 @@ class ChAdaViT(nn.Module):
         # cfg5 224 -> 230 images/s same box; gradient bar of tests/test_model_gpu.py::test_fp8_weight_path_vs_golden unchanged (worst
         # per-tensor norm 6.7e-2 -> 7.1e-2, lowest cosine 0.941 -> 0.937).  CHADAVIT_FP8_DX=0: bf16 dX GEMMs (same-box A/B).
         self.fp8_dx = os.environ.get("CHADAVIT_FP8_DX", "1") == "1"
+        # fp8 path: substrings of weight names whose FORWARD GEMM stays on bf16 operands (e.g. ("blocks.0.self_attn.in_proj",)): the error
+        # budget of the 45 fp8 GEMMs of a pass, measured per GEMM kind and per block in profiles/r05b_fp8_error_budget.md
+        self.fp8_keep_bf16: Tuple[str, ...] = ()
         self._capture_blocks = None  # tests: {block index: None} -> filled with that block's output (packed rows) by the forward
 
     @staticmethod
@@ -194,6 +202,20 @@ class ChAdaViT(nn.Module):
     # ------------------------------------------------------------------------------------------
     # public forward surface
     # ------------------------------------------------------------------------------------------
+    def _expect_pos_accumulation(self):
+        """A backward pass returned `dpos_patch` to autograd: pos_embed.grad (a view of the gradient slab) is complete only after autograd's
+        accumulation into it, which happens once per backward call, some time after the pass's own backward function has returned.  Until
+        then the slab span that holds pos_embed must not be handed to the gradient all-reduce: the pass that fires the span hooks parks that
+        span in `_pos_span_deferred`, and this (persistent, lazily registered) post-accumulate hook releases it."""
+        self._pos_autograd_pending = True
+        if self._pos_hook_handle is None:
+            def _after_accumulate(_p, self=self):
+                self._pos_autograd_pending = False
+                deferred, self._pos_span_deferred = self._pos_span_deferred, None
+                if deferred is not None:
+                    deferred()
+            self._pos_hook_handle = self.pos_embed.register_post_accumulate_grad_hook(_after_accumulate)
+
     def forward(self, x, index, list_num_channels):
         nch = list_num_channels[index]
         if isinstance(nch, int):
@@ -306,6 +328,9 @@ def _linear(m: ChAdaViT, flat: FlatParams, xb, wname: str, bias, epilogue=ops.EP
     """epilogue(xb W^T + bias): bf16 MFMA GEMM, or -- weight_dtype "fp8" -- OCP-MX fp8 operands on the scaled MFMA.
     fp8 only: `xq` = (bytes, scales) of xb when a producing epilogue already quantised it; `emit_q` returns (out, (bytes, scales)) with
     the result quantised by THIS GEMM's epilogue for the next one (out is None when want_out is False)."""
+    if m.weight_dtype == "fp8" and m.fp8_keep_bf16 and any(pat in wname for pat in m.fp8_keep_bf16):
+        out = ops.gemm_nt(xb, flat.w(wname), bias=bias, epilogue=epilogue, aux=aux)
+        return (out, ops.mx8_quantize(out)) if emit_q else out
     if m.weight_dtype == "fp8":
         n, k = flat.shapes[wname]
         if n % 128 == 0 and k % 128 == 0 and epilogue in (ops.EPI_NONE, ops.EPI_RELU, ops.EPI_RESID):
@@ -690,9 +715,19 @@ class _BackboneFn(torch.autograd.Function):
             gpos[1:].add_(dpos)
         elif ctx.pos_needs_grad:
             dpos_patch = dpos  # bicubic-resized rows (other crop sizes): autograd carries dpos back to pos_embed
+            if m.grad_ready_hook is not None and m.pos_embed.requires_grad:
+                m._expect_pos_accumulation()
         flat.publish_grads()
         if hook is not None:
-            hook(flat, *flat.span(["cls_token", "token_learner.proj.bias"]))
+            # the span that holds pos_embed is final HERE only if no part of pos_embed's gradient still travels through autograd: with
+            # bicubic-resized position rows (crops of another size than img_size) `dpos_patch` is added to pos_embed.grad -- a view of the
+            # gradient slab -- by autograd AFTER this function returns.  Reducing the span now would race with that add and drop the term on
+            # the other ranks, so in that case the span is handed over from a one-shot hook that runs once the accumulation has happened.
+            span = flat.span(["cls_token", "token_learner.proj.bias"])
+            if m._pos_autograd_pending:
+                m._pos_span_deferred = lambda hook=hook, flat=flat, span=span: hook(flat, *span)
+            else:
+                hook(flat, *span)
         # what autograd does with saved tensors after a backward without retain_graph: let go of them.  A loss tensor that is kept around
         # (a list of per-step losses) would otherwise keep this pass's crop buffer, index arrays and final activations alive through its
         # graph -- 1-2 GB per step at the bench's batch (found by scratch/r4/fed_soak.py)

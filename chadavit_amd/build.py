@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libchadavit_hip.so")
-SOURCES = ["gemm_nt.hip", "ffn_fused.hip", "ffn_fused_d384.hip", "gemm_tn.hip", "layernorm.hip", "attention.hip", "attention_m32.hip", "attention_bwd_m32.hip", "attention_cls.hip", "tokenizer.hip", "dino_ops.hip", "gemm_mx8.hip", "augment.hip", "host_draw.hip"]
+SOURCES = ["gemm_nt.hip", "ffn_fused.hip", "ffn_fused_d384.hip", "gemm_tn.hip", "layernorm.hip", "attention.hip", "attention_m32.hip", "attention_cls.hip", "tokenizer.hip", "dino_ops.hip", "gemm_mx8.hip", "augment.hip", "host_draw.hip"]
 # -packed-fp32-ops: no v_pk_{mul,add,fma}_f32.  On gfx950 a packed f32 op costs the VALU port 8 cycles -- the same as the two scalar ops it
 # replaces -- and beside MFMAs it stalls the matrix pipe on top (scratch/r3/coissue*.hip: 2 v_pk_fma_f32 per 32x32x16 MFMA = 60 cycles per
 # MFMA against 36 with 2 v_fma_f32).  hipcc forms them from every float4 / float2 expression.  Same-box A/B of the whole step: +1.2 %
@@ -34,20 +34,30 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True, extra_flags=(), lib_path: str = LIB, objdir_name: str = "build") -> str:
-    """extra_flags / lib_path / objdir_name: a second build of the same ABI next to the product one (same-box A/B of compiler
-    options or kernel variants; load it with CHADAVIT_HIP_LIB)."""
+SIDE = os.path.join(ROOT, "scratch", "sidebuild")  # side builds (A/B variants, deliberately broken libraries): OUTSIDE the package
+
+
+def side_lib(tag: str) -> str:
+    return os.path.join(SIDE, tag, f"libchadavit_hip_{tag}.so")
+
+
+def build(force: bool = False, verbose: bool = True, extra_flags=(), side: str | None = None, csrc: str = CSRC) -> str:
+    """side = a tag: a second build of the same ABI (same-box A/B of compiler options / kernel variants) under scratch/sidebuild/<tag>/,
+    never inside the package; load it with CHADAVIT_HIP_LIB=<path> CHADAVIT_ALLOW_FOREIGN_LIB=1.  csrc: another source directory (a
+    checkout of an older commit) for such a build."""
     hipcc = _hipcc()
-    objdir = os.path.join(HERE, objdir_name)
+    lib_path = LIB if side is None else side_lib(side)
+    objdir = os.path.join(HERE, "build") if side is None else os.path.join(SIDE, side)
+    CSRC_ = csrc
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(ROOT, "include", "chadavit_hip.h")]
+    headers = [os.path.join(CSRC_, "common.h"), os.path.join(ROOT, "include", "chadavit_hip.h")]
     jobs = []
     objs = []
     for src in SOURCES:
-        sp = os.path.join(CSRC, src)
+        sp = os.path.join(CSRC_, src)
         op = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(op)
-        deps = [sp] + headers + ([os.path.join(CSRC, "ffn_fused.hip")] if src == "ffn_fused_d384.hip" else [])
+        deps = [sp] + headers + ([os.path.join(CSRC_, "ffn_fused.hip")] if src == "ffn_fused_d384.hip" else [])
         if force or _stale(op, deps):
             jobs.append([hipcc, *FLAGS, *extra_flags, "-c", sp, "-o", op])
 

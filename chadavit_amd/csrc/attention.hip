@@ -1578,14 +1578,8 @@ static int attn_bwd_launch(const chada_bf16* qkv_, const chada_bf16* out_, const
     hipLaunchKernelGGL(attn_delta_kernel, dim3(dgrid), dim3(256), 0, s, out, dout, delta, T, D, H);
     CHADA_CHECK_LAUNCH();
   }
-  // head widths 96 / 192: the 32x32x16-MFMA pair (attention_bwd_m32.hip) is built, correct and measured -- and 3 % (dQ) / 14 % (dK/dV)
-  // SLOWER than the 16x16x32 kernels below at the bench's shapes (profiles/r04b_attention_bwd_m32.md): it stays selectable for A/B runs
-  // (CHADAVIT_ATTN_BWD_M32=1) and reachable as chadavit_attn_bwd_m32; the default is the faster pair.
-  static const int bwd_m32 = getenv("CHADAVIT_ATTN_BWD_M32") ? atoi(getenv("CHADAVIT_ATTN_BWD_M32")) : 0;  // 1 = on; 0 / unset / negative = off
-  if (bwd_m32 > 0 && (dh == 96 || dh == 192)) {
-    const int rest = ((parts & 3) == 1) ? (parts & 4) : parts;   // a lone delta request was served by the pass above
-    return rest ? chadavit_attn_bwd_m32(qkv_, out_, dout_, lse, dqkv_, delta, cu_seqlens, work, n_work, T, D, H, rest, scale, stream) : 0;
-  }
+  // (the 32x32x16-MFMA backward pair of round 4 -- correct, 3 % / 14 % slower than the kernels below -- left the library in round 5:
+  // scratch/r4/attention_bwd_m32.hip.txt, profiles/r04b_attention_bwd_m32.md)
   const dim3 blk(256);
 #define BWD_REG_CASE(DHV, CBV) /* register-staged kernels: head widths without an LDS-DMA instance */                      \
   case DHV:                                                                                                       \

@@ -612,7 +612,7 @@ __global__ __launch_bounds__(256) void knn_vote_kernel(const float* __restrict__
 
 }  // namespace
 
-extern "C" int chadavit_abi_version(void) { return 8; }
+extern "C" int chadavit_abi_version(void) { return 9; }
 
 extern "C" int chadavit_l2norm_fwd(const float* x, chada_bf16* y, float* inv_norm, int M, int N, void* stream) {
   CHADA_ENTRY();

@@ -21,6 +21,7 @@ import contextlib
 import ctypes
 import math
 import random
+import dataclasses
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence, Tuple
 
@@ -324,7 +325,9 @@ class DeviceMultiCropPipeline:
             # crops" / "all local crops" as a view of it (channels_strategies.adjacent_view) instead of a torch.cat copy
             buf = torch.empty((spec.num_crops * nchan, 1, spec.crop_size, spec.crop_size), device=self.device, dtype=torch.float32)
             for k in range(spec.num_crops):
-                cp = next(it) if it is not None else self._draw(spec, shapes, geo)
+                # replayed parameters: the PUBLIC list fields drive the kernels (a caller may have edited them); the draw's private array
+                # forms of the same values are dropped instead of silently taking precedence
+                cp = dataclasses.replace(next(it), arrays=None, jitter_flat=None) if it is not None else self._draw(spec, shapes, geo)
                 used.append(cp)
                 out = buf[k * nchan:(k + 1) * nchan]
                 prep = self._prepare_crop(spec, cp, shapes, offs, geo)

@@ -34,24 +34,41 @@ def tune_allocator_for_ragged_batches(divisions: int = 8) -> bool:
     cached block for every size it has met and asks the driver for a new one whenever none fits -- reserved memory grew 147 -> 206 GiB over 150
     steps of the cfg2-mixed workload at 256 images (hipMalloc stalls: 2 040 images/s) and expandable segments are not supported on this
     platform.  `roundup_power2_divisions` makes the allocator round request sizes to 1/`divisions` of a power of two, so blocks are reused
-    across batches: 118.6 GiB reached after 50 steps and flat from there, 2 290 images/s (scratch/r4/fed_soak.py --mixed).  Applied once per
-    process; `DevicePrefetcher` calls it when its dataset reports more than one channel count.  Returns whether the setting was applied."""
+    across batches: 118.6 GiB reached after 50 steps and flat from there, 2 290 images/s (scratch/r4/fed_soak.py --mixed).
+
+    The setting is PROCESS-WIDE (every allocation is rounded up, by up to 1/`divisions`) and torch re-parses the whole configuration
+    string, so this call (a) is explicit -- `DevicePrefetcher(tune_allocator=True)` or a direct call, never a side effect of building a
+    loader --, (b) APPENDS the option to whatever PYTORCH_HIP_ALLOC_CONF / PYTORCH_CUDA_ALLOC_CONF / PYTORCH_ALLOC_CONF the user set
+    instead of replacing it, (c) leaves a configuration alone that already names a roundup option, and (d) says once what it did.
+    Returns whether the setting was applied."""
     global _ALLOCATOR_TUNED
     if _ALLOCATOR_TUNED or not torch.cuda.is_available():
         return False
+    import logging
+    import os
+    log = logging.getLogger("chadavit_amd.data")
+    user = next((os.environ[k] for k in ("PYTORCH_ALLOC_CONF", "PYTORCH_HIP_ALLOC_CONF", "PYTORCH_CUDA_ALLOC_CONF") if os.environ.get(k)), "")
+    if "roundup_power2_divisions" in user:
+        log.info("allocator: the user's configuration already sets a roundup option (%s): left alone", user)
+        _ALLOCATOR_TUNED = True
+        return False
+    conf = ",".join(x for x in (user.strip().strip(","), f"roundup_power2_divisions:{int(divisions)}") if x)
     try:
         setter = getattr(torch._C, "_accelerator_setAllocatorSettings", None) or torch.cuda.memory._set_allocator_settings
-        setter(f"roundup_power2_divisions:{int(divisions)}")
-    except Exception:  # noqa: BLE001 -- an allocator back end without the option: nothing to tune
+        setter(conf)
+    except Exception as e:  # noqa: BLE001 -- an allocator back end without the option: nothing to tune
+        log.warning("allocator: could not apply %r (%s)", conf, e)
         return False
     _ALLOCATOR_TUNED = True
+    log.warning("allocator: caching-allocator configuration set to %r for this process (requests rounded to 1/%d of a power of two: "
+                "blocks are reused across variable-channel batches)", conf, int(divisions))
     return True
 
 
 class DevicePrefetcher:
     def __init__(self, dataset, batch_sampler: Iterable[Sequence[int]], pipeline, depth: int = 2, workers: int = 8,
                  labels: Optional[Sequence[int]] = None, kernels_on: str = "producer", stream: Optional["torch.cuda.Stream"] = None,
-                 raw_planes: bool = False):
+                 raw_planes: bool = False, tune_allocator: bool = False):
         if kernels_on not in ("consumer", "producer"):
             raise ValueError("kernels_on: 'consumer' or 'producer'")
         self.defer = kernels_on == "consumer" and pipeline.device.type == "cuda"
@@ -63,12 +80,9 @@ class DevicePrefetcher:
         # raw_planes: ask the dataset for the planes in their stored integer type (`read_planes(i, raw=True)`): the pipeline uploads 8 / 16-bit
         # planes as they are and converts on the GPU -- same crops, a quarter / half of the staging copy and the PCIe traffic
         self.read = (lambda i: dataset.read_planes(i, raw=True)) if raw_planes else dataset.read_planes
-        if self.device.type == "cuda" and callable(getattr(dataset, "num_channels", None)):
-            try:
-                if len(set(dataset.num_channels())) > 1:
-                    tune_allocator_for_ragged_batches()
-            except Exception:  # noqa: BLE001 -- a dataset that cannot tell its channel counts cheaply: leave the allocator alone
-                pass
+        # tune_allocator: opt in to `tune_allocator_for_ragged_batches()` (process-wide; see there) -- worth it for variable-channel datasets
+        if tune_allocator and self.device.type == "cuda":
+            tune_allocator_for_ragged_batches()
         self.read_s = 0.0      # host seconds spent decoding (sum over batches; the reader threads' wall time per batch)
         self.batches = 0
 

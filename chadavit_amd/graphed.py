@@ -191,7 +191,8 @@ class GraphedTrainStep:
     # ------------------------------------------------------------------------------------------
     def __call__(self, batch, batch_idx: int = 0) -> torch.Tensor:
         tr, m = self.trainer, self.model
-        m.current_epoch = tr.current_epoch
+        if not isinstance(getattr(type(m), "current_epoch", None), property):   # (read-only on a real LightningModule: trainer.py)
+            m.current_epoch = tr.current_epoch
         if batch_idx == 0:
             m.on_train_epoch_start()
         frozen = tr.current_epoch < m.freeze_last_layer

@@ -44,7 +44,11 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
             torch.cuda.set_device(local)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        # a finite rendezvous / collective timeout: a rank that died must not hold the others for torch's default half hour
+        # (torchrun tears the group down on the first failed worker anyway; this covers launchers that do not)
+        from datetime import timedelta
+        dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                timeout=timedelta(seconds=int(os.environ.get("CHADAVIT_DIST_TIMEOUT_S", "600"))))
     elif torch.cuda.is_available():
         torch.cuda.set_device(local)
     return rank, world, local

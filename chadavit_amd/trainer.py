@@ -66,7 +66,9 @@ class Trainer:
 
     def eager_step(self, batch, batch_idx: int = 0) -> torch.Tensor:
         m = self.model
-        m.current_epoch = self.current_epoch
+        # (a real LightningModule reads `current_epoch` from its trainer -- a read-only property; the stand-in base holds it as an attribute)
+        if not isinstance(getattr(type(m), "current_epoch", None), property):
+            m.current_epoch = self.current_epoch
         if batch_idx == 0:
             self._hook("on_train_epoch_start")
         loss = m.training_step(batch, batch_idx)

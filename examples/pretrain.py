@@ -64,7 +64,9 @@ def main():
     for epoch in range(a.epochs):
         trainer.current_epoch = epoch
         sampler.set_epoch(epoch)
-        loader = DevicePrefetcher(ds, sampler, DeviceMultiCropPipeline(specs, dev, seed=1000 * epoch + rank), depth=2, workers=8)
+        # (variable-channel datasets: opt in to the allocator rounding that keeps reserved memory flat -- process-wide, said once in the log)
+        loader = DevicePrefetcher(ds, sampler, DeviceMultiCropPipeline(specs, dev, seed=1000 * epoch + rank), depth=2, workers=8,
+                                  tune_allocator=len(set(ds.num_channels())) > 1 if callable(getattr(ds, "num_channels", None)) else False)
         for i, batch in enumerate(loader):
             loss = trainer.train_step(batch, i)
             done += 1

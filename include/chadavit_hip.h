@@ -155,14 +155,6 @@ int chadavit_attn_bwd(const chada_bf16* qkv, const chada_bf16* out, const chada_
 int chadavit_attn_bwd_parts(const chada_bf16* qkv, const chada_bf16* out, const chada_bf16* dout, const float* lse,
                             chada_bf16* dqkv, float* delta, const int* cu_seqlens, const int* work, int n_work, int T,
                             int D, int H, int parts, void* stream);
-/* The backward for dh 96 / 192 on v_mfma_f32_32x32x16_bf16 (csrc/attention_bwd_m32.hip; autograd of chada_vit.py:105-111): a wave owns
- * 32 query rows (dQ) or 32 key rows (dK/dV), the saved LSE is the softmax's exponent reference, -delta rides in the dP MFMAs' C operand.
- * `parts` as above (a lone delta request, parts & 3 == 1, returns 3); `scale` = the model's softmax scale.  Built and measured in
- * round 4: correct, and 3 % (dQ) / 14 % (dK/dV) slower than the 16x16x32 pair at the bench's shapes (profiles/r04b_attention_bwd_m32.md),
- * so chadavit_attn_bwd[_parts] dispatch here only with CHADAVIT_ATTN_BWD_M32=1 (A/B runs). */
-int chadavit_attn_bwd_m32(const chada_bf16* qkv, const chada_bf16* out, const chada_bf16* dout, const float* lse, chada_bf16* dqkv,
-                          float* delta, const int* cu_seqlens, const int* work, int n_work, int T, int D, int H, int parts, float scale,
-                          void* stream);
 /* bwd for dh = D/H = 16 -- the reference's DEFAULT constructor (12 heads at D = 192, src/backbones/vit/chada_vit.py:138-139; the
  * notebook's model): heads are widened to 32 lanes with zeros in `workspace` (>= chadavit_attn_bwd_dh16_workspace_bytes, 16-byte
  * aligned, caller-owned) and the dh = 32 kernels run with the model's softmax scale 1/sqrt(16).  Replaces autograd of

@@ -1,10 +1,11 @@
 """Round 4, "prove the new assertions bite": a second build of the library with round 3's QKV-postlogue bug put back (the barrier
 wait of the whole-block kernel's no-grad postlogue is `vmcnt(6)` on EVERY step again, so the last step reads a weight block that
 is still landing: a wrong V third in 1-5 % of the teacher / local-crop rows at bench size).  Nothing of the product changes: the two
-units are compiled from a patched COPY of ffn_fused.hip into chadavit_amd/build_bug/ and linked with the product's other objects.
+units are compiled from a patched COPY of ffn_fused.hip into scratch/sidebuild/postlogue_bug/ (outside the package since round 5) and
+linked with the product's other objects.
 
-    python scratch/r4/postlogue_bug_build.py       ->  chadavit_amd/build_bug/libchadavit_hip_postlogue_bug.so
-    CHADAVIT_HIP_LIB=<that> python -m pytest tests/test_model_gpu.py -m gpu -k "bench_scale_replicated or vs_golden_and_oracle"
+    python scratch/r4/postlogue_bug_build.py       ->  scratch/sidebuild/postlogue_bug/libchadavit_hip_postlogue_bug.so
+    CHADAVIT_HIP_LIB=<that> CHADAVIT_ALLOW_FOREIGN_LIB=1 python -m pytest tests/test_model_gpu.py -m gpu -k "bench_scale_replicated or vs_golden_and_oracle"
 """
 import os
 import shutil
@@ -16,7 +17,7 @@ sys.path.insert(0, ROOT)
 from chadavit_amd import build as B  # noqa: E402
 
 B.build(verbose=False)               # the product objects
-out = os.path.join(B.HERE, "build_bug")
+out = os.path.join(B.SIDE, "postlogue_bug")
 src = os.path.join(out, "csrc")
 os.makedirs(src, exist_ok=True)
 for f in ("common.h", "ffn_fused.hip", "ffn_fused_d384.hip"):

@@ -303,3 +303,36 @@ def test_deferred_kernels_return_the_same_batch_and_a_launch_callable():
         launch()                                       # the kernels need the GPU library's device path
     with pytest.raises(Exception):
         DeviceMultiCropPipeline(specs, "cpu", seed=3)(imgs)
+
+
+def test_allocator_tuning_is_opt_in_and_keeps_the_users_configuration(monkeypatch):
+    """the process-wide allocator rounding is never a side effect of building a DevicePrefetcher; when asked for it is
+    APPENDED to the user's allocator configuration, and a configuration that already sets a roundup option is left alone."""
+    import torch
+    from chadavit_amd.data import loader as L
+    calls = []
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch._C, "_accelerator_setAllocatorSettings", lambda conf: calls.append(conf), raising=False)
+    monkeypatch.setattr(L, "_ALLOCATOR_TUNED", False)
+    for k in ("PYTORCH_ALLOC_CONF", "PYTORCH_HIP_ALLOC_CONF", "PYTORCH_CUDA_ALLOC_CONF"):
+        monkeypatch.delenv(k, raising=False)
+
+    class DS:
+        def num_channels(self):
+            return [1, 3, 5]
+
+        def read_planes(self, i, raw=False):
+            raise AssertionError("not read")
+
+    class Pipe:
+        device = torch.device("cpu")
+
+    L.DevicePrefetcher(DS(), [[0]], Pipe())                 # mixed channel counts, no opt-in: nothing happens
+    assert calls == []
+    monkeypatch.setenv("PYTORCH_HIP_ALLOC_CONF", "max_split_size_mb:512,garbage_collection_threshold:0.8")
+    assert L.tune_allocator_for_ragged_batches() is True
+    assert calls == ["max_split_size_mb:512,garbage_collection_threshold:0.8,roundup_power2_divisions:8"]
+    assert L.tune_allocator_for_ragged_batches() is False   # once per process
+    monkeypatch.setattr(L, "_ALLOCATOR_TUNED", False)
+    monkeypatch.setenv("PYTORCH_HIP_ALLOC_CONF", "roundup_power2_divisions:[256:1,512:2,>:4]")
+    assert L.tune_allocator_for_ragged_batches() is False and len(calls) == 1   # the user's own roundup list wins

@@ -224,6 +224,26 @@ def test_bench_contract_with_two_ranks():
     assert out["config"]["logged_loss_mean_over_ranks"] is not None and "other_workloads" not in out["config"]
 
 
+def test_bench_with_a_dead_rank_fails_fast_instead_of_hanging():
+    """one of two ranks dies (SIGKILL, injected in front of its first timed step) while the other is inside the
+    step's collectives.  The launch, started exactly as the driver starts it, must come back NON-ZERO well inside the timeout and print
+    no result line -- not sit in a collective until somebody kills it."""
+    import time
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, CHADAVIT_DIST_BACKEND="gloo", CHADAVIT_SINGLE_DEVICE="1", CHADAVIT_BENCH_FAULT="1:0", CHADAVIT_DIST_TIMEOUT_S="120")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "16", "--steps", "2", "--warmup", "1",
+           "--no-verify-equal-batch", "--no-launch-profile", "--no-full-width-leg"]
+    t0 = time.time()
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=420)
+    assert r.returncode != 0, r.stdout[-1000:]
+    assert time.time() - t0 < 400
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")], r.stdout[-1000:]
+
+
 DATA_WORKER = r'''
 import os, sys, json, torch, numpy as np
 sys.path.insert(0, os.environ["CHADAVIT_ROOT"])
@@ -315,10 +335,11 @@ def test_disk_to_training_step_on_two_ranks(tmp_path):
     assert abs(a["logged"] - b["logged"]) < 1e-9 and abs(a["logged"] - 0.5 * (a["losses"][-1] + b["losses"][-1])) < 1e-4
 
 
+@pytest.mark.slow
 @pytest.mark.timeout(1200)
 def test_bench_contract_single_gpu_with_all_legs():
     """`python bench.py` as the driver runs it at N = 1 (smaller batch, no CPU baseline): ONE JSON line with the contract's keys, the
-    roofline object, the full-width leg, the cfg3 / cfg5 / cfg1 (eager and hipGraph) / cfg2-at-512 legs without an error entry, and the data-path
+    roofline object, the full-width leg, the cfg2-mixed / cfg3 / cfg5 / cfg1 (hipGraph) / cfg2-at-512 / cfg2-standard legs without an error entry, and the data-path
     leg.  Guards the round-end bench run against a leg that raises."""
     import json
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "32", "--no-cpu-baseline",
@@ -336,15 +357,22 @@ def test_bench_contract_single_gpu_with_all_legs():
     cfg = out["config"]
     assert cfg["images_per_s_with_full_width_last_block"] > 0 and "workload" in cfg
     legs = cfg["other_workloads"]
-    assert set(legs) == {"cfg3", "cfg5", "cfg1", "cfg1-graph", "cfg2-512", "cfg2-standard"} and legs["cfg2-512"]["images_per_gpu"] == 512
+    assert set(legs) == {"cfg2-mixed", "cfg3", "cfg5", "cfg1-graph", "cfg2-512", "cfg2-standard"} and legs["cfg2-512"]["images_per_gpu"] == 512
+    # the data-parallel MECHANISM in a group of one RCCL rank (child process): 15 hand-overs to the communication stream per step
+    w1 = out["rccl"]["world1_mechanism"]
+    assert "error" not in w1, w1
+    assert w1["backend"] == "nccl" and w1["world"] == 1 and w1["spans"] >= 14 and w1["ms_per_step"] > 0 and w1["mechanism_ms_per_step"] is not None
+    # the north star's literal target workload (Tiny/16, 1-10 channels per image) carries its dominant kernel and roofline fraction
+    assert "1-10 channel" in legs["cfg2-mixed"]["workload"] and legs["cfg2-mixed"]["dominant_kernel"] and 0 < legs["cfg2-mixed"]["frac"] < 1
     for name, leg in legs.items():
         assert "error" not in leg, (name, leg)
         assert leg["images_per_s"] > 0 and leg["ms_per_step"] > 0
-    assert legs["cfg1-graph"]["launch"].startswith("one hipGraph") and legs["cfg1"]["launch"] == "eager"   # (no timing assertions here)
+    assert legs["cfg1-graph"]["launch"].startswith("one hipGraph") and legs["cfg3"]["launch"] == "eager"   # (no timing assertions here)
     dp = cfg["data_path"]
     assert "error" not in dp and dp["step_fed_by_pipeline_images_per_s"] > 0 and dp["decode_images_per_s_per_reader_thread"] > 0
 
 
+@pytest.mark.slow
 @pytest.mark.timeout(900)
 def test_example_scripts_run(tmp_path):
     """examples/pretrain.py (synthetic planes -> device augmentation -> 3 DINO steps -> Lightning-shaped checkpoint + optimiser state)

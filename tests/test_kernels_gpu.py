@@ -1326,41 +1326,3 @@ def test_dino_loss_over_more_than_two_student_views(B, V, PR):
     np.testing.assert_allclose(colsum.cpu().numpy(), t.sum(0).numpy(), rtol=1e-5, atol=1e-4)
 
 
-@pytest.mark.parametrize("nch,p,D", [([3, 1, 2], 196, 192), ([1, 14, 15, 16, 30, 31, 32, 33, 63, 64, 65, 127, 128, 129, 200], 1, 192), ([2, 5], 196, 384)])
-def test_attention_backward_m32_variant(nch, p, D):
-    """chadavit_attn_bwd_m32 (csrc/attention_bwd_m32.hip: the backward pair on 32x32x16 MFMAs, opt-in since it measured slower than the
-    default pair) against fp32 torch autograd and against the default kernels on the same inputs, incl. sequence lengths around every
-    tile boundary; delta written by its dQ kernel."""
-    import ctypes
-    from chadavit_amd import ops
-    from chadavit_amd.ragged import RaggedBatch
-    dev = _dev()
-    H = 2
-    rb = RaggedBatch(nch, p, dev)
-    qkv = _rand((rb.T, 3 * D), 1).to(torch.bfloat16).to(dev)
-    dout = _rand((rb.T, D), 2).to(torch.bfloat16).to(dev)
-    out, lse = ops.attn_fwd(qkv, rb.cu_seqlens, rb.work, H)
-    ref = ops.attn_bwd(qkv, out, dout, lse, rb.cu_seqlens, rb.work, H)
-    dqkv = torch.full_like(qkv, float("nan"))
-    delta = torch.empty((H, rb.T), device=dev, dtype=torch.float32)
-    rc = ops.lib().chadavit_attn_bwd_m32(*[ctypes.c_void_p(t.data_ptr()) for t in (qkv, out, dout, lse, dqkv, delta, rb.cu_seqlens, rb.work)],
-                                         ctypes.c_int(rb.n_work), ctypes.c_int(rb.T), ctypes.c_int(D), ctypes.c_int(H), ctypes.c_int(7),
-                                         ctypes.c_float(1.0 / math.sqrt(D // H)), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
-    assert rc == 0, rc
-    torch.cuda.synchronize()
-    assert torch.isfinite(dqkv.float()).all()
-    assert float((dqkv.float() - ref.float()).norm() / ref.float().norm()) <= 8e-3    # two bf16 formulations of the same gradient
-    # fp32 autograd
-    x = qkv.float().cpu().requires_grad_(True)
-    q, k, v = x.split(D, dim=1)
-    dh, cu = D // H, rb.host_cu_seqlens
-    outs = []
-    for i in range(len(cu) - 1):
-        a, b = cu[i], cu[i + 1]
-        outs.append(torch.cat([torch.softmax(q[a:b, h * dh:(h + 1) * dh] @ k[a:b, h * dh:(h + 1) * dh].T / dh ** 0.5, dim=1) @ v[a:b, h * dh:(h + 1) * dh]
-                               for h in range(H)], dim=1))
-    (torch.cat(outs) * dout.float().cpu()).sum().backward()
-    for sl in (slice(0, D), slice(D, 2 * D), slice(2 * D, 3 * D)):
-        assert float((dqkv[:, sl].float().cpu() - x.grad[:, sl]).norm() / x.grad[:, sl].norm()) <= 1.5e-2
-    dref = (dout.float() * out.float()).view(rb.T, H, dh).sum(-1).t()
-    assert float((delta - dref).abs().max()) <= 1e-3 * float(dref.abs().max()) + 1e-4

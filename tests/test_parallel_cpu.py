@@ -429,3 +429,90 @@ def test_dino_loss_module_accepts_the_standard_multicrop_view_count_and_checks_s
         lf(torch.zeros(8, 64), torch.zeros(4, 64))      # 8 rows are 4 views of 2 images, not 5 (and not the 2 global views)
     with pytest.raises(RuntimeError, match="5 views"):
         lf(torch.zeros(9, 64), torch.zeros(4, 64))      # not a whole number of views
+
+
+LIGHTNING_BOUNDARY = r"""
+import inspect, re, sys, types
+import torch.nn as nn
+
+# ---- a stand-in `pytorch_lightning` installed BEFORE the product is imported: faithful where the product could trip over the real one --
+# `trainer` is a property that raises while unattached, `current_epoch` / `global_step` are READ-ONLY properties fed by the trainer
+class LightningModule(nn.Module):
+    def __init__(self, *a, **k):
+        super().__init__()
+        self._trainer = None
+    @property
+    def trainer(self):
+        if self._trainer is None:
+            raise RuntimeError(f"{type(self).__qualname__} is not attached to a `Trainer`.")
+        return self._trainer
+    @trainer.setter
+    def trainer(self, t):
+        self._trainer = t
+    @property
+    def current_epoch(self):
+        return self._trainer.current_epoch if self._trainer is not None else 0
+    @property
+    def global_step(self):
+        return self._trainer.global_step if self._trainer is not None else 0
+    def log(self, *a, **k): pass
+    def log_dict(self, *a, **k): pass
+pl = types.ModuleType("pytorch_lightning"); pl.LightningModule = LightningModule
+sys.modules["pytorch_lightning"] = pl
+sys.path.insert(0, ROOT)
+
+import chadavit_amd.methods.dino as D
+assert issubclass(D.DINO, LightningModule), D.DINO.__mro__          # the Lightning-installed branch of the boundary (methods/dino.py)
+
+# ---- SURVEY 8(b): the hook set with Lightning's signatures
+want = {"configure_optimizers": [], "on_train_start": [], "on_train_epoch_start": [], "training_step": ["batch", "batch_idx"],
+        "on_after_backward": [], "optimizer_zero_grad": ["epoch", "batch_idx", "optimizer"], "on_train_batch_end": ["outputs", "batch", "batch_idx"],
+        "validation_step": ["batch", "batch_idx"], "on_validation_epoch_end": [], "forward": ["X", "index"], "momentum_forward": ["X", "index"],
+        "extract_features": ["batch"]}
+for name, lead in want.items():
+    params = [p for p in inspect.signature(getattr(D.DINO, name)).parameters.values()][1:]
+    names = [p.name for p in params]
+    assert names[:len(lead)] == lead, (name, names)
+    assert all(p.default is not inspect.Parameter.empty or p.kind in (p.VAR_POSITIONAL, p.VAR_KEYWORD) for p in params[len(lead):]), (name, names)
+assert isinstance(inspect.getattr_static(D.DINO, "add_and_assert_specific_cfg"), staticmethod)
+assert isinstance(D.DINO.learnable_params, property) and isinstance(D.DINO.momentum_pairs, property)
+
+# ---- INTEGRATION.md section A, executed as written: the maintainer's src/mi355x.py against a stand-in `src.methods`
+src = types.ModuleType("src"); methods = types.ModuleType("src.methods"); methods.METHODS = {}; src.methods = methods
+sys.modules["src"] = src; sys.modules["src.methods"] = methods
+code = re.search(r"```python\n(# src/mi355x.py.*?)```", open(ROOT + "/INTEGRATION.md").read(), re.S).group(1)
+ns = {}
+exec(code, ns)
+ns["install"]()
+ref_cv = sys.modules["src.backbones.vit.chada_vit"]
+assert inspect.ismodule(ref_cv) and inspect.isclass(ref_cv.ChAdaViT)
+from oracle import refshim
+model = methods.METHODS["dino"](refshim.dino_cfg(embed_dim=192, num_prototypes=256))      # main_pretrain.py:87
+assert isinstance(model, LightningModule)
+assert isinstance(model.backbone, ref_cv.ChAdaViT) and isinstance(model.momentum_backbone, ref_cv.ChAdaViT)   # base.py:526-528
+assert sys.modules["src.losses.dino"].DINOLoss is type(model.dino_loss_func)
+assert callable(sys.modules["src.data.channels_strategies"].one_channel_collate_fn)
+assert hasattr(sys.modules["src.utils.momentum"], "MomentumUpdater") and hasattr(sys.modules["src.utils.momentum"], "initialize_momentum_params")
+
+# ---- the bundled loop on such a module: attaches, configures the optimiser, and never writes Lightning's read-only properties
+from chadavit_amd.trainer import Trainer
+tr = Trainer(max_epochs=3, steps_per_epoch=5).attach(model)
+assert model.trainer is tr and tr.optimizer is not None
+tr.current_epoch = 2
+assert model.current_epoch == 2
+print("LIGHTNING-BOUNDARY-OK")
+"""
+
+
+def test_lightning_boundary(tmp_path):
+    """the boundary exercised the way the reference would.  A `pytorch_lightning` stand-in is installed BEFORE the
+    product is imported (fresh interpreter): `DINO` must then subclass its LightningModule, expose SURVEY 8(b)'s hook set with
+    Lightning's signatures, and INTEGRATION.md section A's `install()` -- executed from the document itself -- must make
+    `isinstance(model.backbone, src.backbones.vit.chada_vit.ChAdaViT)` true (base.py:526-528).  Construction only: no GPU."""
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    script = tmp_path / "lightning_boundary.py"
+    script.write_text("ROOT = %r\n" % root + LIGHTNING_BOUNDARY)
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0 and "LIGHTNING-BOUNDARY-OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
