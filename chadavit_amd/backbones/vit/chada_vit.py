@@ -411,7 +411,8 @@ def _block_fwd(m: ChAdaViT, flat: FlatParams, i: int, x, rb: RaggedBatch, save: 
         if m.weight_dtype == "fp8":
             # linear1's epilogue hands linear2 its fp8 operand (no quantise pass over the hidden activation); the bf16 copy is written
             # only when the backward needs it
-            hid, hidq = _linear(m, flat, x1, b + "linear1.weight", flat.f(b + "linear1.bias"), ops.EPI_RELU, xq=x1q, emit_q=True, want_out=save)
+            hid, hidq = _linear(m, flat, x1, b + "linear1.weight", flat.f(b + "linear1.bias"), ops.EPI_RELU, xq=x1q, emit_q=True,
+                                want_out=save or any(pat in b + "linear2.weight" for pat in m.fp8_keep_bf16))
             z = _linear(m, flat, hid, b + "linear2.weight", flat.f(b + "linear2.bias"), ops.EPI_RESID, x1, xq=hidq)
         else:
             hid = _linear(m, flat, x1, b + "linear1.weight", flat.f(b + "linear1.bias"), ops.EPI_RELU)
@@ -460,7 +461,8 @@ def _last_block_cls_fwd(m: ChAdaViT, flat: FlatParams, i: int, x, rb: RaggedBatc
     ln2 = (flat.f(b + "norm2.weight"), flat.f(b + "norm2.bias"), m.blocks[i].norm2.eps)
     if fq:
         x1, x1q = ops.layernorm_fwd(y, g1, b1, eps, mean=stc[0] if save else None, rstd=stc[1] if save else None, emit_q=True)
-        hid, hidq = _linear(m, flat, x1, b + "linear1.weight", flat.f(b + "linear1.bias"), ops.EPI_RELU, xq=x1q, emit_q=True, want_out=save)
+        hid, hidq = _linear(m, flat, x1, b + "linear1.weight", flat.f(b + "linear1.bias"), ops.EPI_RELU, xq=x1q, emit_q=True,
+                            want_out=save or any(pat in b + "linear2.weight" for pat in m.fp8_keep_bf16))
         z = _linear(m, flat, hid, b + "linear2.weight", flat.f(b + "linear2.bias"), ops.EPI_RESID, x1, xq=hidq)
     else:
         x1 = ops.layernorm_fwd(y, g1, b1, eps, mean=stc[0] if save else None, rstd=stc[1] if save else None)

@@ -8,7 +8,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from oracle import procedural as P
 from chadavit_amd.backbones import vit_channels
-import chadavit_amd.backbones.vit.chada_vit as CV
+import importlib
+CV = importlib.import_module('chadavit_amd.backbones.vit.chada_vit')
 from chadavit_amd.data.channels_strategies import one_channel_collate_fn
 dev = torch.device("cuda:0")
 g = np.load(os.path.join(ROOT, "tests", "golden", "backbone_base.npz"))

@@ -138,6 +138,17 @@ def test_fp8_weight_path_vs_golden(fp8_dx):
     ref = torch.from_numpy(g["cls0"])
     assert _cos(cls, ref) >= 0.99, _cos(cls, ref)
     print("fp8 backbone_base: CLS cosine", _cos(cls, ref), "rel-L2", _rel(cls, ref))
+    # the margin above that bar is the ELEMENT FORMAT's, not slack in a kernel (profiles/r05b_fp8_error_budget.md): every block adds the same
+    # independent ~3.2 % (e4m3: 3 mantissa bits, both operands quantised), the squares add up to rel-L2 ~0.11 over 12 blocks.  The budget
+    # model is held too: with the 24 attention projections back on bf16 operands (fp8_keep_bf16) half of the error variance must be gone --
+    # a kernel that adds error beyond the format's breaks this line long before the 0.99 above
+    if not fp8_dx:
+        m.fp8_keep_bf16 = ("in_proj", "out_proj")
+        with torch.no_grad():
+            cls_half = m(crops[0].to(dev), 0, ncl if isinstance(ncl[0], list) else [ncl])
+        m.fp8_keep_bf16 = ()
+        assert _cos(cls_half, ref) >= 0.996 and _rel(cls_half, ref) <= 0.09, (_cos(cls_half, ref), _rel(cls_half, ref))
+        assert _rel(cls_half, ref) <= 0.8 * _rel(cls, ref), (_rel(cls_half, ref), _rel(cls, ref))
     # ---- a whole training step (student fwd + bwd, teacher fwd, loss) against the reference's Base step golden
     g = np.load(os.path.join(GOLDEN, "step_base_c10.npz"))
     D, PR = int(g["D"]), int(g["P"])
