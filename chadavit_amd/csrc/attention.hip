@@ -1186,8 +1186,11 @@ __device__ __forceinline__ void attn_dq_tile(BufRsrc kg, BufRsrc vg, bf16_t* __r
   }
 }
 
+// One 16-row query block per wave (CB = 1: dh 192, where two spill) fits three blocks per CU: 175 registers at two waves per SIMD, 168 with 4
+// spilled outside the loop at three -- and the third wave is worth 6 %: 1 017 -> 957 us on cfg3's global pass, 257 -> 241 us on its local
+// one (same box, interleaved; profiles/r05g_dq192_three_blocks_per_cu.log).
 template <int DH, int CB, bool FUSE_DELTA>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_dma_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+__global__ __launch_bounds__(256, (CB == 1 && DH <= 192 ? 3 : 2)) void attn_bwd_dq_dma_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                           const float* __restrict__ lse, float* __restrict__ delta,
                                                           bf16_t* __restrict__ dqkv, const int* __restrict__ cu,
                                                           const int* __restrict__ work, int T, int D, int H, float scale,
@@ -1595,6 +1598,8 @@ static int attn_bwd_launch(const chada_bf16* qkv_, const chada_bf16* out_, const
   switch (dh) {
     BWD_REG_CASE(32, 2) BWD_REG_CASE(64, 2) BWD_REG_CASE(128, 2) BWD_REG_CASE(256, 1)
     case 96:
+      // (dh 96 keeps two query blocks per wave at two blocks per CU: one block per wave at three blocks per CU -- 123 registers -- measured
+      // 1 123 against 991 us: half the MFMAs per K / V fragment read outweighs the third wave; profiles/r05g_dq192_three_blocks_per_cu.log)
       if ((parts & 2) && fuse_delta)
         hipLaunchKernelGGL((attn_bwd_dq_dma_kernel<96, 2, true>), dim3(n_work * H), blk, 0, s, qkv, dout, lse, delta, dqkv, cu_seqlens, work, T, D, H, scale, out);
       else if (parts & 2)

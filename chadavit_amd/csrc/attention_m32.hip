@@ -40,6 +40,7 @@ constexpr int TILE = 128;  // query rows per work item (the host's work list, ch
 #ifndef CHADA_M32_KV32
 #define CHADA_M32_KV32 0
 #endif
+// (dh 192 at three waves per SIMD: 41 spilled registers, 1 103 against 632 us on cfg3's global pass -- stays at two; round 5)
 constexpr bool KV32_AT_DH96 = CHADA_M32_KV32 != 0;   // 32-key tiles at dh 96 too: 24 KiB of LDS per block, five blocks per CU instead of three
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;

@@ -99,7 +99,7 @@ __device__ __forceinline__ void tn_dma_and_read(BufRsrc ag, unsigned abytes, Buf
 }
 
 template <int BI, int BJ, int NST>
-__global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const bf16_t* __restrict__ A, int lda,
+__global__ __launch_bounds__(256, (NST == 2 ? 3 : 2)) void gemm_tn_dma_kernel(const bf16_t* __restrict__ A, int lda,
                                                           const bf16_t* __restrict__ B, int ldb,
                                                           float* __restrict__ part, float* __restrict__ part_cs, int T,
                                                           int I, int J, int tchunk, int nsplits) {
@@ -260,7 +260,18 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
 
 template <int BI, int BJ>
 void launch_tn(const bf16_t* A, int lda, const bf16_t* B, int ldb, float* part, float* part_cs, int T, int I, int J,
-               int tchunk, int splits, hipStream_t s) {
+               int tchunk, int splits, hipStream_t s, bool occ3 = false) {
+  if constexpr (BI == 128 && BJ == 192) {
+    // 128 x 192 tiles: TWO stages (40 KB) and 167 registers let three blocks live on a CU instead of two with three stages -- a third wave
+    // per SIMD to issue into the gaps of the other two is worth more than the deeper ring: 1 155 -> 1 116 us at 1 206 272 x 2048 x 192
+    // (4.67 -> 4.84 TB/s), -5 % on the Small shapes (profiles/r05g_tn_three_blocks_per_cu.log).  The mirrored 192 x 128 tile spills 15
+    // registers under the same bound and runs 2x slower: it keeps three stages and two blocks.
+    if (occ3) {
+      hipLaunchKernelGGL((gemm_tn_dma_kernel<BI, BJ, 2>), dim3((I / BI) * (J / BJ) * ((splits + 7) / 8 * 8)), dim3(256), 0, s, A, lda,
+                         B, ldb, part, part_cs, T, I, J, tchunk, splits);
+      return;
+    }
+  }
   hipLaunchKernelGGL((gemm_tn_dma_kernel<BI, BJ, 3>), dim3((I / BI) * (J / BJ) * ((splits + 7) / 8 * 8)), dim3(256), 0, s, A, lda,
                      B, ldb, part, part_cs, T, I, J, tchunk, splits);
 }
@@ -303,10 +314,13 @@ extern "C" int chadavit_gemm_tn(const chada_bf16* A_, int lda, const chada_bf16*
     const double t_full = fmax(2.0 * T * I * J / 0.95e15, 2.0 * T * (double)(I + J) / 4.6e12);   // seconds at full occupancy
     double best = 1e30;
     int best_n = 0;
+    const char* occ_env = getenv("CHADA_TN_OCC3");
+    const bool occ3_ = !(occ_env && atoi(occ_env) == 0) && bi == 128 && bj == 192;   // (CHADA_TN_OCC3=0: the three-stage kernel, A/B runs)
+    const int slots = occ3_ ? 96 : 64;
     for (int n = 1; n <= 64; ++n) {
       if (8 * n > max_by_t || 8 * n > max_by_ws) break;
-      const int rounds = (tiles * n + 63) / 64;
-      const double t = t_full * (64.0 * rounds) / ((double)tiles * n) + 8.0 * n * (double)I * J * 8.0 / 4.0e12;
+      const int rounds = (tiles * n + slots - 1) / slots;
+      const double t = t_full * ((double)slots * rounds) / ((double)tiles * n) + 8.0 * n * (double)I * J * 8.0 / 4.0e12;
       if (t < best) { best = t; best_n = n; }
     }
     splits = best_n ? 8 * best_n : (int)((max_by_ws < max_by_t ? max_by_ws : max_by_t) < 1 ? 1 : (max_by_ws < max_by_t ? max_by_ws : max_by_t));
@@ -322,8 +336,10 @@ extern "C" int chadavit_gemm_tn(const chada_bf16* A_, int lda, const chada_bf16*
   splits = (T + tchunk - 1) / tchunk;
   float* part = workspace;
   float* part_cs = colsumA ? workspace + (size_t)splits * I * J : nullptr;
+  const char* occ_env2 = getenv("CHADA_TN_OCC3");
+  const bool occ3 = !(occ_env2 && atoi(occ_env2) == 0);
 #define TN_CASE(a, b) \
-  if (bi == a && bj == b) launch_tn<a, b>(A, lda, B, ldb, part, part_cs, T, I, J, tchunk, splits, s);
+  if (bi == a && bj == b) launch_tn<a, b>(A, lda, B, ldb, part, part_cs, T, I, J, tchunk, splits, s, occ3);
   TN_CASE(128, 192) TN_CASE(192, 128) TN_CASE(128, 128) TN_CASE(64, 192) TN_CASE(192, 64) TN_CASE(128, 64)
   TN_CASE(64, 128) TN_CASE(64, 64) TN_CASE(192, 192)
 #undef TN_CASE
