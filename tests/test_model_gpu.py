@@ -1068,7 +1068,8 @@ def test_training_step_with_batchnorm_in_the_head_vs_golden_and_oracle():
 
 
 @pytest.mark.parametrize("name,R_,rows,weight_dtype", [("step_tiny_multicrop", 170, 600780, "bf16"), ("step_small_mixed", 70, 274820, "bf16"),
-                                                       ("step_base_c10", 25, 127500, "bf16"), ("step_base_c10", 25, 127500, "fp8"),
+                                                       pytest.param("step_base_c10", 25, 127500, "bf16", marks=pytest.mark.slow),   # (23 s; the fp8 twin stays in the default run)
+                                                       ("step_base_c10", 25, 127500, "fp8"),
                                                        # 2.35 x the bench's rows: activations past 32-bit element and byte offsets
                                                        pytest.param("step_tiny_multicrop", 400, 1413600, "bf16", marks=pytest.mark.slow)])
 def test_bench_scale_replicated_batch_vs_golden(name, R_, rows, weight_dtype):
