@@ -183,11 +183,34 @@ __device__ __forceinline__ void ffn_core(BufRsrc wrs, unsigned blk_bytes, bf16_t
   constexpr int HROW = 72;
   constexpr int NPEND = WRITE_H ? RT * 2 : 1;
   const int li = l & 15, g = l >> 4;
-  if (issue) {  // record f of a block goes to wave f % NWV
+// The instances that write H / dpre (two LDS stages: the slab takes the third's room) deal the next block's six LDS-DMA pieces out over the
+// iteration's steps instead of issuing them as one burst behind the barrier: all eight waves of a CU reach their burst together and queue at
+// the CU's one vector-memory path, and these instances have their H stores in the same queue.  Training whole-block kernel 2 759 -> 2 712 us,
+// backward dX 2 080 -> 2 061 us at 1 206 272 rows; cfg2 +0.2 %, cfg3 +0.5 % (three interleaved rounds: profiles/r05k_ffn_spread_dma.log).  On the
+// three-stage no-grad instances the same change gave the step nothing back (the pieces land one iteration later there anyway): burst kept.
+#ifndef CHADA_FFN_SPREAD_DMA
+#define CHADA_FFN_SPREAD_DMA 1
+#endif
+  constexpr int PPW = BLK_FRAGS / NWV;   // LDS-DMA pieces per wave and block
+  constexpr int NSTEP_ALL = DO_P ? BLK_FRAGS / 2 : ((DO_G1 ? KS1 : 0) + (DO_G2 ? NT2 / 2 : 0));
+  constexpr bool SPREAD = CHADA_FFN_SPREAD_DMA && WRITE_H && NSTEP_ALL >= PPW;
+  auto issue_piece = [&](int i) {  // record f of a block goes to wave f % NWV
+    const int f = w + NWV * i;
+    lds_dma16(wrs, dst + f * FRAG_ELEMS, l * 16, blk_bytes + f * (FRAG_ELEMS * 2));
+  };
+  auto issue_at = [&](int sidx) {  // the block's pieces dealt out over the steps instead of going out as one burst
+    if constexpr (SPREAD) {
+      if (issue) {
 #pragma unroll
-    for (int i = 0; i < BLK_FRAGS / NWV; ++i) {
-      const int f = w + NWV * i;
-      lds_dma16(wrs, dst + f * FRAG_ELEMS, l * 16, blk_bytes + f * (FRAG_ELEMS * 2));
+        for (int i = 0; i < PPW; ++i)
+          if ((i * NSTEP_ALL) / PPW == sidx) issue_piece(i);
+      }
+    }
+  };
+  if constexpr (!SPREAD) {
+    if (issue) {
+#pragma unroll
+      for (int i = 0; i < PPW; ++i) issue_piece(i);
     }
   }
   __builtin_amdgcn_sched_barrier(0);  // the DMA goes out FIRST: free of the alias edge, the scheduler would sink it below the math
@@ -197,6 +220,7 @@ __device__ __forceinline__ void ffn_core(BufRsrc wrs, unsigned blk_bytes, bf16_t
     pr[0][1] = lds_read8(st + FRAG_ELEMS + l * 8);
 #pragma unroll
     for (int sidx = 0; sidx < BLK_FRAGS / 2; ++sidx) {
+      issue_at(sidx);
       if (sidx + 1 < BLK_FRAGS / 2) {
         pr[(sidx + 1) & 1][0] = lds_read8(st + (2 * sidx + 2) * FRAG_ELEMS + l * 8);
         pr[(sidx + 1) & 1][1] = lds_read8(st + (2 * sidx + 3) * FRAG_ELEMS + l * 8);
@@ -244,6 +268,7 @@ __device__ __forceinline__ void ffn_core(BufRsrc wrs, unsigned blk_bytes, bf16_t
     if (i < NSTEP) rd_step(i, fr[i]);
 #pragma unroll
   for (int sidx = 0; sidx < NSTEP; ++sidx) {
+    issue_at(sidx);
     if (sidx + PD < NSTEP) rd_step(sidx + PD, fr[(sidx + PD) % (PD + 1)]);
     __builtin_amdgcn_sched_barrier(0);
     if (sidx < G1S) {
