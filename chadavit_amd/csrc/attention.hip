@@ -877,19 +877,25 @@ __device__ __forceinline__ void attn_dkv_tile(BufRsrc qg, BufRsrc dog, BufRsrc l
   constexpr int NRW = KVT * (DH / 8) / 256;  // 1 KiB records per wave and tensor
   constexpr int TILE_E = KVT * DH;           // bf16 elements of one tensor's tile
   const int g = l >> 4, li = l & 15;
-  if (issue) {
-    const int r0 = (q0 + 1) * KVT;
-#pragma unroll
-    for (int i = 0; i < NRW; ++i) {
+  // dh 384 (one block per CU, 13 LDS-DMA instructions per wave and tile): the next tile's pieces are dealt out over the first steps of the tile
+  // instead of going out as one burst behind the barrier -- 1 865 -> 1 801 us on cfg5's pass; at dh 96 / 192 (7 instructions, two blocks per CU) the
+  // same change is neutral (1 203 vs 1 205 us, 1 278 vs 1 278): burst kept there (profiles/r05k_ffn_spread_dma.log)
+  constexpr bool SPREAD = DH > 192;
+  const int r0 = (q0 + 1) * KVT;
+  auto issue_piece = [&](int i) {   // i < NRW: the Q and dO records; NRW: lse / delta (wave 0)
+    if (i < NRW) {
       const unsigned row = (unsigned)min(r0 + rec_row[i], len - 1);
       lds_dma16(qg, dst + (w + 4 * i) * 512, (row * ldq + rec_col[i]) * 2, 0);
       lds_dma16(dog, dst + TILE_E + (w + 4 * i) * 512, (row * ldo + rec_col[i]) * 2, 0);
-    }
-    if (w == 0 && l < KVT) {  // lse / delta of the tile: 4 bytes per lane
+    } else if (w == 0 && l < KVT) {  // lse / delta of the tile: 4 bytes per lane
       const int qr = min(r0 + l, len - 1);
       lds_dma4(lg, dst + 2 * TILE_E, qr * 4, 0);
       lds_dma4(dg, dst + 2 * TILE_E + 2 * KVT, qr * 4, 0);
     }
+  };
+  if (issue && (!SPREAD || idle)) {
+#pragma unroll
+    for (int i = 0; i <= NRW; ++i) issue_piece(i);
   }
   __builtin_amdgcn_sched_barrier(0);  // the DMA goes out FIRST: free of the alias edge, the scheduler would sink it below the math
   if (idle) return;  // (wave-uniform) none of this wave's keys exists: it only feeds the DMA and the barriers
@@ -928,6 +934,9 @@ __device__ __forceinline__ void attn_dkv_tile(BufRsrc qg, BufRsrc dog, BufRsrc l
 #pragma unroll
     for (int st = 0; st < 2 * KS; ++st) {
       const int q2 = st / KS, ks = st % KS, cur = st & 1;
+      if constexpr (SPREAD) {   // one piece per step of the first half instead of a burst behind the barrier
+        if (issue && k2 == 0 && st <= NRW) issue_piece(st);
+      }
       if (st + 1 < 2 * KS) row_read(k2 * 2 * KS + st + 1, qfr[cur ^ 1], dofr[cur ^ 1]);
       else tr_read(k2, 0, dot[0], qtf[0]);  // first transposed pair: lands under the softmax
       __builtin_amdgcn_sched_barrier(0);
