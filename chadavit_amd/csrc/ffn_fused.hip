@@ -25,8 +25,15 @@
 // names (chada_int_*_d384); the public entry points below dispatch on D.
 #ifndef FFN_FD
 #define FFN_FD 192
+// (the tiling can be overridden from the command line for A/B builds.  Measured at D = 192, 603 136 rows, same box, against 4 x 32 rows at two waves
+// per SIMD -- training 1 398 / no-grad 1 018 / backward dX 1 064 us: eight waves x 16 rows at FOUR waves per SIMD (-DFFN_NW=8 -DFFN_RT=1
+// -DFFN_MIN_WAVES=4; 16-80 spilled registers in the whole-block instances) 1 523 / 1 202 / 1 244, the same without forcing the registers
+// (one block per CU for the whole-block instances) 1 650 / 1 270 / 1 238, six waves x 16 rows at three per SIMD 1 823 / 1 458 / 1 385: one
+// row tile per wave doubles the LDS fragment reads per MFMA, and that costs more than the extra waves hide -- profiles/r05m_block_tilings.log)
+#ifndef FFN_NW
 #define FFN_NW 4
 #define FFN_RT 2
+#endif
 #define FFN_PRIMARY 1
 #define FFN_NAME(x) chadavit_##x
 #else
@@ -322,7 +329,10 @@ __device__ __forceinline__ void ffn_core(BufRsrc wrs, unsigned blk_bytes, bf16_t
 // l holds the 16 bits of chunk k (low half: even k) described at ffn_core.  M/32 tiles x FF/256 groups x 1 KiB = M * FF / 8 bytes,
 // written as whole 1 KiB records; the backward dX instance reads it with the same lane mapping, nothing else looks inside.
 template <int RT, bool WRITE_H, bool PRO = false, int MODE = 0>
-__global__ __launch_bounds__(64 * NWV, (RT * NWV <= 8 ? 2 : 1)) void ffn_fwd_kernel(const bf16_t* __restrict__ X, int ldx,
+#ifndef FFN_MIN_WAVES
+#define FFN_MIN_WAVES (RT * NWV <= 8 ? 2 : 1)
+#endif
+__global__ __launch_bounds__(64 * NWV, FFN_MIN_WAVES) void ffn_fwd_kernel(const bf16_t* __restrict__ X, int ldx,
                                                                          const bf16_t* __restrict__ packed,
                                                                          const float* __restrict__ b1,
                                                                          const float* __restrict__ b2,
