@@ -38,6 +38,74 @@ PEAK_HBM_GBS = 8000.0
 PEAK_MXFP8_TFLOPS = 5000.0  # dense MX-scaled fp8 MFMA (same guide)
 SUSTAINED_BF16_TFLOPS = 1750.0  # measured: what the MFMA pipes sustain on random bf16 operands under the power budget (see roofline)
 
+# the power model of the part, measured (profiles/r05n_power_and_clock_under_each_kernel.log, scratch/sstore/mfma_rate.hip): package cap 1 400 W,
+# every hot kernel of the step sits AT it with the shader clock pulled down to 1.66-2.0 GHz; idle 293 W; back-to-back bf16 MFMAs on random operands
+# reach 1 750 TFLOP/s at the cap => 0.63 W per TFLOP/s; a plain fill writes 6.8 TB/s at 973 W => 100 W per TB/s of HBM traffic
+POWER_CAP_W, POWER_IDLE_W, W_PER_TFLOPS_BF16, W_PER_TBS_HBM = 1400.0, 293.0, 0.63, 100.0
+
+
+class PowerSampler:
+    """Board power and shader clock of this rank's GPU (sysfs hwmon of its PCI function), sampled from a thread over the timed steps."""
+
+    def __init__(self, torch, dev):
+        import glob
+        self.dir, self.rows, self._stop, self._th = None, [], False, None
+        try:
+            pr = torch.cuda.get_device_properties(dev)
+            bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            cand = glob.glob(f"/sys/bus/pci/devices/{bdf}/hwmon/hwmon*")
+            if cand and os.path.exists(os.path.join(cand[0], "power1_input")):
+                self.dir = cand[0]
+        except Exception:
+            self.dir = None
+        self.idle = self._read()
+
+    def _read(self):
+        if self.dir is None:
+            return None
+        try:
+            with open(os.path.join(self.dir, "power1_input")) as f:
+                pw = int(f.read()) / 1e6
+            with open(os.path.join(self.dir, "freq1_input")) as f:
+                fr = int(f.read()) / 1e6
+            return pw, fr
+        except (OSError, ValueError):
+            return None
+
+    def start(self):
+        if self.dir is None:
+            return
+        import threading
+
+        def loop():
+            while not self._stop:
+                r = self._read()
+                if r is not None:
+                    self.rows.append(r)
+                time.sleep(0.02)
+        self._th = threading.Thread(target=loop, daemon=True)
+        self._th.start()
+
+    def stop(self):
+        if self._th is None:
+            return None
+        self._stop = True
+        self._th.join()
+        if not self.rows:
+            return None
+        cap = None
+        try:
+            with open(os.path.join(self.dir, "power1_cap")) as f:
+                cap = int(f.read()) / 1e6
+        except (OSError, ValueError):
+            pass
+        n = len(self.rows)
+        return {"board_w": round(sum(r[0] for r in self.rows) / n, 1), "board_w_max": round(max(r[0] for r in self.rows), 1),
+                "cap_w": cap, "sclk_mhz": round(sum(r[1] for r in self.rows) / n, 1),
+                "before_first_launch": None if self.idle is None else {"board_w": round(self.idle[0], 1), "sclk_mhz": round(self.idle[1], 1)},
+                "samples": n, "source": "hwmon power1_input / freq1_input every 20 ms over the timed steps"}
+
+
 WORKLOADS = {
     # name: (embed_dim, channels spec, n_global, n_local, prototypes, per-GPU batch)
     "cfg2": dict(desc="ChAda-ViT-Tiny/16, fixed 3-channel 224x224, DINO 2 global + 8 local crops", D=192, channels="3",
@@ -852,6 +920,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: chadavit_amd has no CPU path")
     dev = torch.device("cuda", local)
+    power = PowerSampler(torch, dev) if rank == 0 else None   # (its constructor reads the idle figures before the first launch)
     wl = dict(WORKLOADS[args.workload])
     if args.batch:
         wl["batch"] = args.batch
@@ -871,6 +940,8 @@ def main():
     if gs is not None:
         gs.reducer.timing = True   # HIP events around the compute <- communication hand-over of every timed step
     barrier()
+    if power is not None:
+        power.start()
     t0 = time.perf_counter()
     last = None
     fault = os.environ.get("CHADAVIT_BENCH_FAULT")   # "rank:step" -- test hook: that rank dies (SIGKILL) in front of that timed step
@@ -883,6 +954,7 @@ def main():
     dt_local = time.perf_counter() - t0   # this rank's own time to finish its K steps (before waiting for the others)
     barrier()
     dt = time.perf_counter() - t0
+    power_timed = power.stop() if power is not None else None
     comm_timing = None
     rank_ms = None
     if gs is not None:   # (world > 1, or the collectives forced in a group of one rank)
@@ -989,6 +1061,19 @@ def main():
         if prof_summary is not None:
             roof, out["launch_profile_top"] = roofline_object(prof_summary, model, nch, wl)
         out["roofline"] = roof
+        # the roof that binds on real operands is the package power cap (see POWER_CAP_W): board power and shader clock over the timed steps,
+        # and the dominant kernel priced against the part's measured power model -- what its MFMA rate and HBM traffic cost by themselves
+        if power_timed is not None:
+            out["power"] = dict(power_timed)
+            out["power"]["whole_step_model_w"] = {"idle": POWER_IDLE_W, "mfma": round(W_PER_TFLOPS_BF16 * step_tflops, 1),
+                                                  "note": "idle + 0.63 W per executed bf16 TFLOP/s (MFMA-only loop on random operands: 1 750 TFLOP/s at the cap); "
+                                                          "HBM traffic, LDS, VALU and the L2 weight streams are the rest of board_w"}
+        if roof is not None and roof.get("bound") == "mfma" and roof.get("hbm_gbs") is not None and roof.get("peak") == PEAK_BF16_TFLOPS:
+            ess = POWER_IDLE_W + W_PER_TFLOPS_BF16 * roof["achieved"] + W_PER_TBS_HBM * roof["hbm_gbs"] / 1e3
+            roof["power_model"] = {"cap_w": POWER_CAP_W, "idle_w": POWER_IDLE_W, "w_per_tflops_bf16_random_operands": W_PER_TFLOPS_BF16,
+                                   "w_per_tbs_hbm": W_PER_TBS_HBM, "essential_w": round(ess, 1), "essential_frac_of_cap": round(ess / POWER_CAP_W, 4),
+                                   "note": "this kernel runs at the cap (profiles/r05n_power_and_clock_under_each_kernel.log); essential = idle + its "
+                                           "MFMA rate and its HBM traffic priced at the part's measured W per TFLOP/s and W per TB/s"}
         if tokens_per_rank is not None:
             out["config"]["tokens_per_rank"] = tokens_per_rank
             out["config"]["tokens_per_rank_spread"] = round(max(tokens_per_rank) / min(tokens_per_rank) - 1.0, 4)

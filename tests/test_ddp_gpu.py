@@ -354,6 +354,12 @@ def test_bench_contract_single_gpu_with_all_legs():
     assert out["n_gpus"] == 1 and out["steps"] == 2 and out["value"] > 0 and out["dtype"] == "bf16" and out["vs_baseline"] is None
     rf = out["roofline"]
     assert rf["bound"] in ("mfma", "hbm") and 0 < rf["frac"] < 1 and rf["avg_us"] > 0 and rf["kernel"]
+    # the power cap is the roof that binds on real operands: when the box exposes the GPU's hwmon the line carries board power and shader clock over
+    # the timed steps, and the dominant kernel priced against the part's measured power model
+    if out.get("power") is not None:
+        assert 300 < out["power"]["board_w"] <= 1.05 * (out["power"]["cap_w"] or 1400.0) and 500 < out["power"]["sclk_mhz"] <= 2500 and out["power"]["samples"] > 0
+    if rf.get("power_model") is not None:
+        assert 0.3 < rf["power_model"]["essential_frac_of_cap"] < 1.05
     cfg = out["config"]
     assert cfg["images_per_s_with_full_width_last_block"] > 0 and "workload" in cfg
     legs = cfg["other_workloads"]
