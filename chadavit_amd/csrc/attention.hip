@@ -256,6 +256,9 @@ __global__ __launch_bounds__(256, (DH <= 96 ? 2 : 1)) void attn_fwd_kernel(const
 // two stages apart and would put the whole load latency of tile kt+1 in front of the math of tile kt.  (The kernel must
 // also keep a single __shared__ object: with several, the LDS lowering replaces these scopes by per-variable ones.)
 template <int DH>
+__device__ __forceinline__ int dkv_swz(int row);   // (defined with the backward kernels' row-major stages)
+
+template <int DH>
 struct FwdDmaCfg {
   static constexpr int KS = (DH + 31) / 32, DB = DH / 16;
   // keys per tile: 64 up to dh = 96, 32 above -- the same 24 records (24 KiB) per stage and 48 MFMAs per wave and tile, so a
@@ -269,7 +272,7 @@ struct FwdDmaCfg {
   static constexpr int STAGE = NR * 512;
 };
 
-template <int DH, int CB, bool MASKED>
+template <int DH, int CB, bool MASKED, bool RM = false>
 __device__ __forceinline__ void attn_fwd_tile(BufRsrc qb, bf16_t* __restrict__ dst,
                                               const bf16_t* __restrict__ sK, bool issue, int kt, int len, int qrow0, unsigned ldu, float c,
                                               int w, int l, const int (&rec_row)[FwdDmaCfg<DH>::NRW],
@@ -294,28 +297,53 @@ __device__ __forceinline__ void attn_fwd_tile(BufRsrc qb, bf16_t* __restrict__ d
   // left alone hipcc issues each read right in front of its MFMAs and waits for it.  The first two V fragments are
   // requested before the softmax and land under it.
   f32x4 s[CB][KB];
-  bf16x8 fr[3];
+  constexpr int PD = 2;   // look-ahead of the fragment ring in steps (dh 384: 3, 4, 6 and 10 measured the same as 2)
+  bf16x8 fr[PD + 1];
   constexpr int NS = KB * KS, NP = K2 * DB;
   // last tile of the sequence: only the 16-key blocks that hold a valid key are multiplied / exponentiated (len = 589:
   // 13 keys = one block of four) -- wave-uniform branches, identical results (the skipped scores are -inf, their P is 0)
   const int nvb = MASKED ? min(KB, (len - kt * KVT + 15) >> 4) : KB;
-  fr[0] = lds_read8(sK + l * 8);
-  if constexpr (NS > 1) fr[1] = lds_read8(sK + 512 + l * 8);
+  // RM: the stage is the ROW-MAJOR image of the K and V tiles (whole 128-byte lines per LDS-DMA instruction, chunks XOR-swizzled on the source
+  // side as in the backward kernels' stages: dkv_swz) -- K fragments by row reads, V^T fragments by the transpose read of the row-major tile
+  const int li_ = l & 15;
+  auto k_read = [&](int st) {
+    if constexpr (RM) {
+      const int row = (st / KS) * 16 + li_, ch = ((st % KS) * 4 + g) ^ dkv_swz<DH>(row);
+      return lds_read8(sK + row * DH + ch * 8);
+    } else {
+      return lds_read8(sK + st * 512 + l * 8);
+    }
+  };
+  auto v_read = [&](int st) {
+    if constexpr (RM) {
+      const int k2 = st / DB, db = st % DB;
+      const int trow = k2 * 32 + 4 * g + (li_ >> 2);
+      const int ch = (2 * db + ((li_ & 3) >> 1)) ^ dkv_swz<DH>(trow);
+      const int off = trow * DH + ch * 8 + (li_ & 1) * 4;
+      return __builtin_shufflevector(lds_read_tr4(sV + off), lds_read_tr4(sV + off + 16 * DH), 0, 1, 2, 3, 4, 5, 6, 7);
+    } else {
+      return lds_read_tr8(sV + st * 512, 16);
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < PD; ++i)
+    if (i < NS) fr[i] = k_read(i);
 #pragma unroll
   for (int st = 0; st < NS; ++st) {
     const int kb = st / KS, ks = st % KS;
-    if (st + 2 < NS) fr[(st + 2) % 3] = lds_read8(sK + (st + 2) * 512 + l * 8);
+    if (st + PD < NS) fr[(st + PD) % (PD + 1)] = k_read(st + PD);
     __builtin_amdgcn_sched_barrier(0);
     if (!MASKED || kb < nvb) {
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb)
-        s[cb][kb] = (ks == 0) ? mfma16(fr[st % 3], qf[cb][0], f32x4{0.f, 0.f, 0.f, 0.f}) : mfma16(fr[st % 3], qf[cb][ks], s[cb][kb]);
+        s[cb][kb] = (ks == 0) ? mfma16(fr[st % (PD + 1)], qf[cb][0], f32x4{0.f, 0.f, 0.f, 0.f}) : mfma16(fr[st % (PD + 1)], qf[cb][ks], s[cb][kb]);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
-  bf16x8 vr[3];
-  vr[0] = lds_read_tr8(sV, 16);
-  if constexpr (NP > 1) vr[1] = lds_read_tr8(sV + 512, 16);
+  bf16x8 vr[PD + 1];
+#pragma unroll
+  for (int i = 0; i < PD; ++i)
+    if (i < NP) vr[i] = v_read(i);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int cb = 0; cb < CB; ++cb) {
@@ -366,11 +394,11 @@ __device__ __forceinline__ void attn_fwd_tile(BufRsrc qb, bf16_t* __restrict__ d
 #pragma unroll
   for (int st = 0; st < NP; ++st) {
     const int k2 = st / DB, db = st % DB;
-    if (st + 2 < NP) vr[(st + 2) % 3] = lds_read_tr8(sV + (st + 2) * 512, 16);
+    if (st + PD < NP) vr[(st + PD) % (PD + 1)] = v_read(st + PD);
     __builtin_amdgcn_sched_barrier(0);
     if (!MASKED || 2 * k2 < nvb) {
 #pragma unroll
-      for (int cb = 0; cb < CB; ++cb) o[cb][db] = mfma16(vr[st % 3], pf[k2][cb], o[cb][db]);
+      for (int cb = 0; cb < CB; ++cb) o[cb][db] = mfma16(vr[st % (PD + 1)], pf[k2][cb], o[cb][db]);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -385,7 +413,7 @@ __device__ __forceinline__ void attn_fwd_tile(BufRsrc qb, bf16_t* __restrict__ d
 //                      hardware transpose read (two ds_read_b64_tr_b16), 256 contiguous bytes per 32-lane phase.
 // Same arithmetic (and bit-identical results) as attn_fwd_kernel.
 // =====================================================================================
-template <int DH, int CB>
+template <int DH, int CB, bool RM = false>
 __global__ __launch_bounds__(64 * FwdDmaCfg<DH>::NW, (DH <= 192 ? 2 : 1)) void attn_fwd_dma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                            float* __restrict__ lse, const int* __restrict__ cu,
                                                            const int* __restrict__ work, int T, int D, int H, float scale) {
@@ -395,6 +423,8 @@ __global__ __launch_bounds__(64 * FwdDmaCfg<DH>::NW, (DH <= 192 ? 2 : 1)) void a
   using C = FwdDmaCfg<DH>;
   constexpr int KS = C::KS, DB = C::DB, KVT = C::KVT, NKR = C::NKR, NR = C::NR, NRW = C::NRW, STAGE = C::STAGE, NW = C::NW;
   constexpr int QPB = NW * 16 * CB;  // query rows per block
+  // (dh 384, the CU's only block: THREE stages with a counted wait -- tile t+2 requested while tile t is consumed -- and fragment rings four to ten
+  // steps deep were built and measured: 880 against 885-893 us and no change; scratch/r5/attention_fwd_rowmajor_3stage_ring.patch, profiles/r05o_*)
   __shared__ __attribute__((aligned(16))) bf16_t smem[2 * STAGE];
 
   const int tid = threadIdx.x, l = tid & 63, g = l >> 4, li = l & 15;
@@ -442,7 +472,12 @@ __global__ __launch_bounds__(64 * FwdDmaCfg<DH>::NW, (DH <= 192 ? 2 : 1)) void a
 #pragma unroll
   for (int i = 0; i < NRW; ++i) {
     const int r = w + NW * i;
-    if (r < NKR) {
+    if constexpr (RM) {   // piece r = 64 consecutive 16-byte chunks of the row-major K (r < NKR) / V image; source chunk un-swizzled
+      static_assert(!RM || (NR == 2 * NKR && DH % 32 == 0), "row-major stages: K and V tiles of equal size");
+      const int id = (r % NKR) * 64 + l, row = id / (DH / 8), ch = id % (DH / 8);
+      rec_row[i] = row;
+      rec_col[i] = (r < NKR ? D : 2 * D) + (ch ^ dkv_swz<DH>(row)) * 8;
+    } else if (r < NKR) {
       rec_row[i] = (r / KS) * 16 + li;
       rec_col[i] = D + (r % KS) * 32 + g * 8;
     } else {
@@ -466,12 +501,12 @@ __global__ __launch_bounds__(64 * FwdDmaCfg<DH>::NW, (DH <= 192 ? 2 : 1)) void a
     // tile kt has landed (LDS-DMA completion is visible only through the issuing wave's vmcnt) and everybody is done
     // reading the other stage
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    attn_fwd_tile<DH, CB, false>(qrs, smem + ((kt + 1) & 1) * STAGE, smem + (kt & 1) * STAGE, true, kt, len, qrow0, ldu, c, w, l,
-                                 rec_row, rec_col, qf, o, m, ls);
+    attn_fwd_tile<DH, CB, false, RM>(qrs, smem + ((kt + 1) & 1) * STAGE, smem + (kt & 1) * STAGE, true, kt, len, qrow0, ldu, c, w, l,
+                                     rec_row, rec_col, qf, o, m, ls);
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  attn_fwd_tile<DH, CB, true>(qrs, smem + (nkt & 1) * STAGE, smem + ((nkt - 1) & 1) * STAGE, false, nkt - 1, len, qrow0, ldu, c, w, l,
-                              rec_row, rec_col, qf, o, m, ls);
+  attn_fwd_tile<DH, CB, true, RM>(qrs, smem + (nkt & 1) * STAGE, smem + ((nkt - 1) & 1) * STAGE, false, nkt - 1, len, qrow0, ldu, c, w, l,
+                                  rec_row, rec_col, qf, o, m, ls);
 #pragma unroll
   for (int cb = 0; cb < CB; ++cb) {
     const float lt = rows_sum(ls[cb]);
@@ -1533,6 +1568,19 @@ extern "C" int chadavit_attn_fwd(const chada_bf16* qkv_, chada_bf16* out_, float
   // head widths 96 / 192: the 32x32x16-MFMA forward (attention_m32.hip).  CHADAVIT_ATTN_FWD_M32=-1 keeps the 16x16x32 kernels below
   // (same-box A/B); 1 / 2 select its other softmax variants.
   static const int m32_variant = getenv("CHADAVIT_ATTN_FWD_M32") ? atoi(getenv("CHADAVIT_ATTN_FWD_M32")) : 0;
+  // CHADAVIT_ATTN_FWD_RM=1: the 16x16x32 forward on ROW-MAJOR stages (whole 128-byte lines per LDS-DMA instruction), dh 96 / 192 / 384
+  static const int fwd_rm = getenv("CHADAVIT_ATTN_FWD_RM") ? atoi(getenv("CHADAVIT_ATTN_FWD_RM")) : 0;
+  if (fwd_rm > 0 && (dh == 96 || dh == 192 || dh == 384)) {
+    const bf16_t* qkv = reinterpret_cast<const bf16_t*>(qkv_);
+    bf16_t* out = reinterpret_cast<bf16_t*>(out_);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const float scale = 1.0f / sqrtf((float)dh);
+    if (dh == 96) hipLaunchKernelGGL((attn_fwd_dma_kernel<96, 2, true>), dim3(n_work * H), dim3(256), 0, s, qkv, out, lse, cu_seqlens, work, T, D, H, scale);
+    else if (dh == 192) hipLaunchKernelGGL((attn_fwd_dma_kernel<192, 2, true>), dim3(n_work * H), dim3(256), 0, s, qkv, out, lse, cu_seqlens, work, T, D, H, scale);
+    else hipLaunchKernelGGL((attn_fwd_dma_kernel<384, 1, true>), dim3(n_work * H), dim3(512), 0, s, qkv, out, lse, cu_seqlens, work, T, D, H, scale);
+    CHADA_CHECK_LAUNCH();
+    return 0;
+  }
   if (m32_variant >= 0 && (dh == 96 || dh == 192))
     return chadavit_attn_fwd_m32(qkv_, out_, lse, cu_seqlens, work, n_work, T, D, H, m32_variant, stream);
   const bf16_t* qkv = reinterpret_cast<const bf16_t*>(qkv_);

@@ -333,6 +333,50 @@ def test_attention_fwd_bwd(nch, p, D, H):
     _close(dqkv[:, :D], g[:, :D], 3e-2, 3e-2 * scale, "dQ")
 
 
+def test_attention_fwd_row_major_stages_and_m32_at_dh384():
+    """Two forward instances that the default dispatch does not use, kept for their measurements (profiles/r05o_*): (a) the 16x16x32
+    forward on ROW-MAJOR LDS stages (CHADAVIT_ATTN_FWD_RM=1: whole 128-byte lines per LDS-DMA instruction, chunks swizzled on the source side;
+    the switch is read once per process, hence the child process); (b) the 32x32x16 forward at dh 384 (one wave per SIMD), called directly.
+    Both against fp32 torch on ragged batches incl. the 1961-token sequence and a last tile of 13 keys, LSE included."""
+    import subprocess, sys, os
+    code = r"""
+import ctypes, math, sys, torch
+sys.path.insert(0, %r)
+from chadavit_amd import ops
+from chadavit_amd._lib import lib
+from chadavit_amd.ragged import RaggedBatch
+dev = torch.device("cuda:0")
+def ref(qkv, cu, H):
+    D = qkv.shape[1] // 3; dh = D // H
+    q, k, v = qkv.float().split(D, dim=1)
+    outs, lses = [], []
+    for i in range(len(cu) - 1):
+        s, e = cu[i], cu[i + 1]
+        qi, ki, vi = (x[s:e].reshape(e - s, H, dh).transpose(0, 1) for x in (q, k, v))
+        sc = qi @ ki.transpose(1, 2) / math.sqrt(dh)
+        outs.append((torch.softmax(sc, -1) @ vi).transpose(0, 1).reshape(e - s, D)); lses.append(torch.logsumexp(sc, -1))
+    return torch.cat(outs, 0), torch.cat(lses, 1)
+for D, nch, p in ((192, [3, 1, 10, 5], 196), (192, [1, 3, 2], 36), (384, [10, 2, 3], 196), (768, [1, 10, 3], 196), (768, [2, 10], 36)):
+    rb = RaggedBatch(nch, p, dev)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    qkv = torch.randn((rb.T, 3 * D), generator=g).bfloat16().to(dev)
+    o_ref, l_ref = ref(qkv, rb.host_cu_seqlens, 2)
+    o, l = ops.attn_fwd(qkv, rb.cu_seqlens, rb.work, 2)
+    assert float((o.float() - o_ref).abs().max()) < 2e-2 and float((l - l_ref).abs().max()) < 2e-3, ("row-major", D, nch)
+    if D == 768:
+        o2 = torch.empty_like(o); l2 = torch.empty_like(l)
+        for variant in (0, 1):
+            rc = lib().chadavit_attn_fwd_m32(ops._ptr(qkv), ops._ptr(o2), ops._ptr(l2), ops._ptr(rb.cu_seqlens), ops._ptr(rb.work), ctypes.c_int(rb.n_work),
+                                             ctypes.c_int(rb.T), ctypes.c_int(D), ctypes.c_int(2), ctypes.c_int(variant), ops._stream())
+            assert rc == 0
+            assert float((o2.float() - o_ref).abs().max()) < 2e-2 and float((l2 - l_ref).abs().max()) < 2e-3, ("m32 at dh 384", variant, nch)
+print("ok")
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CHADAVIT_ATTN_FWD_RM="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-4000:]
+
+
 @pytest.mark.parametrize("D", [192, 384, 768])
 def test_attention_lengths_around_the_tile_boundaries(D):
     """Sequences of 2 .. 257 tokens straddling every 16 / 32 / 64 / 128-row boundary: the last tile of the LDS-DMA kernels
