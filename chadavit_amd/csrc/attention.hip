@@ -258,6 +258,16 @@ __global__ __launch_bounds__(256, (DH <= 96 ? 2 : 1)) void attn_fwd_kernel(const
 template <int DH>
 __device__ __forceinline__ int dkv_swz(int row);   // (defined with the backward kernels' row-major stages)
 
+// -DCHADA_FWD_TIMELINE (side builds only, scratch/r5/fwd_timeline.py): wave 0 of every block sums s_memtime differences per phase of the tile
+#ifdef CHADA_FWD_TIMELINE
+__device__ unsigned long long g_fwd_tl[4096 * 8 * 8];   // [block][wave][slot]
+#define TL_NOW() __builtin_amdgcn_s_memtime()
+#define TL_ADD(slot, a, b) tl[slot] += (b) - (a)
+#else
+#define TL_NOW() 0ull
+#define TL_ADD(slot, a, b) ((void)0)
+#endif
+
 template <int DH>
 struct FwdDmaCfg {
   static constexpr int KS = (DH + 31) / 32, DB = DH / 16;
@@ -278,8 +288,9 @@ __device__ __forceinline__ void attn_fwd_tile(BufRsrc qb, bf16_t* __restrict__ d
                                               int w, int l, const int (&rec_row)[FwdDmaCfg<DH>::NRW],
                                               const unsigned (&rec_col)[FwdDmaCfg<DH>::NRW],
                                               const bf16x8 (&qf)[CB][FwdDmaCfg<DH>::KS], f32x4 (&o)[CB][DH / 16], float (&m)[CB],
-                                              float (&ls)[CB]) {
+                                              float (&ls)[CB], unsigned long long (&tl)[8]) {
   using C = FwdDmaCfg<DH>;
+  [[maybe_unused]] const unsigned long long tl0 = TL_NOW();
   constexpr int KS = C::KS, DB = C::DB, KVT = C::KVT, KB = C::KB, K2 = C::K2, NKR = C::NKR, NR = C::NR, NRW = C::NRW;
   const int g = l >> 4;
   if (issue) {
@@ -292,6 +303,8 @@ __device__ __forceinline__ void attn_fwd_tile(BufRsrc qb, bf16_t* __restrict__ d
   }
   __builtin_amdgcn_sched_barrier(0);  // the DMA goes out FIRST: free of the alias edge, the scheduler would sink it below the math
   if (qrow0 >= len) return;  // (wave-uniform) none of this wave's query rows exists: it only feeds the DMA and the barriers
+  [[maybe_unused]] const unsigned long long tl1 = TL_NOW();
+  TL_ADD(1, tl0, tl1);   // DMA issue
   const bf16_t* sV = sK + NKR * 512;
   // The fragment reads run TWO steps ahead of the MFMAs that consume them (ring of three, pinned with sched_barrier):
   // left alone hipcc issues each read right in front of its MFMAs and waits for it.  The first two V fragments are
@@ -340,6 +353,8 @@ __device__ __forceinline__ void attn_fwd_tile(BufRsrc qb, bf16_t* __restrict__ d
     }
     __builtin_amdgcn_sched_barrier(0);
   }
+  [[maybe_unused]] const unsigned long long tl2 = TL_NOW();
+  TL_ADD(2, tl1, tl2);   // S^T MFMAs (+ their fragment reads)
   bf16x8 vr[PD + 1];
 #pragma unroll
   for (int i = 0; i < PD; ++i)
@@ -391,6 +406,8 @@ __device__ __forceinline__ void attn_fwd_tile(BufRsrc qb, bf16_t* __restrict__ d
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb) pf[k2][cb] = pack8(s[cb][2 * k2], s[cb][2 * k2 + 1]);
   __builtin_amdgcn_sched_barrier(0);
+  [[maybe_unused]] const unsigned long long tl3 = TL_NOW();
+  TL_ADD(3, tl2, tl3);   // softmax
 #pragma unroll
   for (int st = 0; st < NP; ++st) {
     const int k2 = st / DB, db = st % DB;
@@ -402,6 +419,8 @@ __device__ __forceinline__ void attn_fwd_tile(BufRsrc qb, bf16_t* __restrict__ d
     }
     __builtin_amdgcn_sched_barrier(0);
   }
+  [[maybe_unused]] const unsigned long long tl4 = TL_NOW();
+  TL_ADD(4, tl3, tl4);   // O^T MFMAs (+ reads)
 }
 
 // =====================================================================================
@@ -490,6 +509,8 @@ __global__ __launch_bounds__(64 * FwdDmaCfg<DH>::NW, (DH <= 192 ? 2 : 1)) void a
   const int nkt = (len + KVT - 1) / KVT;
   const int qrow0 = qt * TILE + part * QPB + w * 16 * CB;  // first query row of this wave
   const BufRsrc qrs = make_rsrc(qbase);  // LDS-DMA through a buffer resource: see lds_dma16
+  unsigned long long tl[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+  [[maybe_unused]] const unsigned long long tl_start = TL_NOW();
   // tile 0: no LDS read follows before the first barrier, issued bare
 #pragma unroll
   for (int i = 0; i < NRW; ++i) {
@@ -500,13 +521,20 @@ __global__ __launch_bounds__(64 * FwdDmaCfg<DH>::NW, (DH <= 192 ? 2 : 1)) void a
   for (int kt = 0; kt < nkt - 1; ++kt) {
     // tile kt has landed (LDS-DMA completion is visible only through the issuing wave's vmcnt) and everybody is done
     // reading the other stage
+    [[maybe_unused]] const unsigned long long tb0 = TL_NOW();
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    [[maybe_unused]] const unsigned long long tb1 = TL_NOW();
+    if (kt == 0) TL_ADD(5, tl_start, tb1); else TL_ADD(0, tb0, tb1);   // slot 5: block start -> first tile ready; slot 0: wait + barrier
     attn_fwd_tile<DH, CB, false, RM>(qrs, smem + ((kt + 1) & 1) * STAGE, smem + (kt & 1) * STAGE, true, kt, len, qrow0, ldu, c, w, l,
-                                     rec_row, rec_col, qf, o, m, ls);
+                                     rec_row, rec_col, qf, o, m, ls, tl);
   }
+  [[maybe_unused]] const unsigned long long tb0 = TL_NOW();
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  [[maybe_unused]] const unsigned long long tb1 = TL_NOW();
+  TL_ADD(0, tb0, tb1);
   attn_fwd_tile<DH, CB, true, RM>(qrs, smem + (nkt & 1) * STAGE, smem + ((nkt - 1) & 1) * STAGE, false, nkt - 1, len, qrow0, ldu, c, w, l,
-                                  rec_row, rec_col, qf, o, m, ls);
+                                  rec_row, rec_col, qf, o, m, ls, tl);
+  [[maybe_unused]] const unsigned long long tl_loop_end = TL_NOW();
 #pragma unroll
   for (int cb = 0; cb < CB; ++cb) {
     const float lt = rows_sum(ls[cb]);
@@ -514,6 +542,14 @@ __global__ __launch_bounds__(64 * FwdDmaCfg<DH>::NW, (DH <= 192 ? 2 : 1)) void a
     store_row_blocks<DB>(out + (size_t)(seq0 + min(qrow[cb], len - 1)) * D + h * DH, qrow[cb] < len, o[cb], inv, g);
     if (g == 0 && qrow[cb] < len) lse[(size_t)h * T + seq0 + qrow[cb]] = (m[cb] + log2f(lt)) * LN2;
   }
+#ifdef CHADA_FWD_TIMELINE
+  if (l == 0 && blockIdx.x < 4096 && w < 8) {
+    const unsigned long long tl_end = TL_NOW();
+    tl[6] = tl_end - tl_loop_end;   // epilogue issue
+    tl[7] = tl_end - tl_start;      // block life
+    for (int i = 0; i < 8; ++i) g_fwd_tl[(blockIdx.x * 8 + w) * 8 + i] = tl[i];
+  }
+#endif
 }
 
 // =====================================================================================
@@ -1556,6 +1592,11 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const bf16_t* __restric
 }  // namespace
 
 extern "C" int chadavit_attn_tile_rows(void) { return TILE; }
+#ifdef CHADA_FWD_TIMELINE
+extern "C" int chadavit_debug_read_fwd_timeline(void* dst, int n) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_fwd_tl), (size_t)n * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 #define ATTN_DISPATCH(DHV, CALL) \
   case DHV: { constexpr int DH_ = DHV; CALL; break; }
