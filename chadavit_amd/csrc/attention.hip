@@ -553,6 +553,206 @@ __global__ __launch_bounds__(64 * FwdDmaCfg<DH>::NW, (DH <= 192 ? 2 : 1)) void a
 }
 
 // =====================================================================================
+// forward at dh = 384 with the two waves of every SIMD in COMPLEMENTARY phases (round 5; profiles/r05o_*, section 4: in attn_fwd_dma_kernel<384>
+// both waves of a SIMD leave the tile's barrier together, multiply together and exponentiate together -- 768 cycles of MFMAs in ~3 600 per wave
+// and tile, nobody covering the other's non-matrix phases).  Here the block's eight waves are two halves (A = waves 0-3, B = 4-7; wave w and w + 4
+// share a SIMD) that run the SAME program one segment apart, two segments and two barriers per key tile:
+//   X_t (matrix):     O += P(t-1) V(t-1)   then   S(t) = K(t) Q^T          -- 48 MFMAs, their fragment reads, nothing else
+//   Y_t (everything else):  softmax of S(t) -> P(t), rescale of O, and the LDS-DMA issue of a later tile
+// A runs X at even segments and Y at odd ones, B the other way round: beside every matrix segment sits the partner's softmax / DMA segment.
+// Stages (fragment-major records as in attn_fwd_dma_kernel): K tiles in a ring of TWO, V tiles in a ring of THREE (120 KiB) -- K(t) is read at
+// segments 2t (A) and 2t+1 (B), V(t) at 2t+2 and 2t+3 -- so that every refill is issued by the half that is in its Y segment when the slot falls
+// free: B fetches K(t+2) in its Y_t, A fetches V(t+1) in its Y_t; each wave waits for its own pieces (vmcnt(0)) at the end of its next X segment,
+// the barrier behind it publishes them.  Same arithmetic and the same order of operations as attn_fwd_dma_kernel<384>: bit-identical results.
+// =====================================================================================
+template <int DH>
+__global__ __launch_bounds__(512, 1) void attn_fwd_pair_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse,
+                                                               const int* __restrict__ cu, const int* __restrict__ work, int T, int D, int H,
+                                                               float scale) {
+  constexpr int KS = DH / 32, DB = DH / 16, KVT = 32, NKR = 2 * KS, NVR = DB;   // 1 KiB records of a K tile (kb, ks) / of a V tile (db)
+  constexpr int KSLOT = NKR * 512, VSLOT = NVR * 512, NPW = NKR / 4;            // bf16 elements per slot; pieces per wave and tile
+  static_assert(NKR == NVR && NKR % 4 == 0, "K and V tiles of equal size, split over the four waves of a half");
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * KSLOT + 3 * VSLOT];
+  const int tid = threadIdx.x, l = tid & 63, g = l >> 4, li = l & 15;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool halfB = w >= 4;
+  const int wq = w & 3;
+  const WorkItem it = decode_work<1>(work, H);
+  const int b = it.b, qt = it.t, h = it.h;
+  if (b < 0) return;
+  const int seq0 = cu[b], len = cu[b + 1] - seq0;
+  if (qt * TILE >= len) return;
+  const size_t ld = 3 * (size_t)D;
+  const bf16_t* qbase = qkv + (size_t)seq0 * ld + h * DH;
+  const float c = scale * LOG2E;
+  const int qrow = qt * TILE + w * 16 + li, qrow0 = qt * TILE + w * 16;
+  const bool idle = qrow0 >= len;   // (wave-uniform) none of this wave's query rows exists: it only feeds the DMA and the barriers
+  bf16x8 qf[KS];
+  {
+    const int qr = min(qrow, len - 1);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qbase + (size_t)qr * ld + ks * 32 + g * 8);
+  }
+  f32x4 o[DB];
+#pragma unroll
+  for (int db = 0; db < DB; ++db) o[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m = -INFINITY, ls = 0.f;
+  // this wave's pieces of a tile: half B fetches K records, half A V records (record r = wq + 4 i)
+  int rec_row[NPW];
+  unsigned rec_col[NPW];
+#pragma unroll
+  for (int i = 0; i < NPW; ++i) {
+    const int r = wq + 4 * i;
+    if (halfB) {
+      rec_row[i] = (r / KS) * 16 + li;
+      rec_col[i] = D + (r % KS) * 32 + g * 8;
+    } else {
+      rec_row[i] = l >> 1;
+      rec_col[i] = 2 * D + r * 16 + (l & 1) * 8;
+    }
+  }
+  const unsigned ldu = 3u * (unsigned)D;
+  const int nkt = (len + KVT - 1) / KVT;
+  const BufRsrc qrs = make_rsrc(qbase);
+  int opq = 0;
+  asm volatile("" : "+s"(opq));   // (the LDS bases go through an opaque zero: see ffn_fused.hip)
+  bf16_t* const sKb = smem + opq;
+  bf16_t* const sVb = smem + 2 * KSLOT + opq;
+  auto fetch = [&](int kt, bf16_t* __restrict__ dst) {   // this wave's NPW pieces of tile kt (K for half B, V for half A)
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+      const unsigned off = (unsigned)min(kt * KVT + rec_row[i], len - 1) * ldu + rec_col[i];
+      lds_dma16(qrs, dst + (wq + 4 * i) * 512, off * 2, 0);
+    }
+  };
+  // ---- the two segment bodies.  Everything that reads a stage lives in these (restrict-scoped pointers: no vmcnt(0) drain in front of the reads)
+  f32x4 sacc[2];
+  bf16x8 pf;
+  auto seg_x = [&](const bf16_t* __restrict__ sV, const bf16_t* __restrict__ sK, auto do_pv_tag, auto do_s_tag) {
+    constexpr bool DO_PV = decltype(do_pv_tag)::value, DO_S = decltype(do_s_tag)::value;
+    if (idle) return;
+    // one ring of three over the 24 V^T fragments (transpose reads) and the 24 K fragments (row reads).  The S^T steps alternate between the two
+    // 16-key blocks: each block's 12 MFMAs are a dependent chain, and with the partner wave in its Y segment nothing else fills the gaps of ONE chain
+    constexpr int NPV = DB, NS = 2 * KS;
+    constexpr int FIRST = DO_PV ? 0 : NPV, LAST = DO_S ? NPV + NS : NPV;
+#ifndef CHADA_PAIR_ABL
+#define CHADA_PAIR_ABL 0   // ablations for timing only (wrong results): 1 = no refills, 2 = no fragment reads, 4 = no MFMAs, 8 = no softmax
+#endif
+    auto rd = [&](int st) {   // step st >= NPV: k-step (st - NPV) / 2 of key block (st - NPV) % 2
+      if constexpr ((CHADA_PAIR_ABL & 2) != 0) return qf[st % KS];
+      if (st < NPV) return lds_read_tr8(sV + st * 512, 16);
+      const int kb = (st - NPV) % 2, ks = (st - NPV) / 2;
+      return lds_read8(sK + (kb * KS + ks) * 512 + l * 8);
+    };
+    bf16x8 fr[3];
+    fr[FIRST % 3] = rd(FIRST);
+    fr[(FIRST + 1) % 3] = rd(FIRST + 1);
+#pragma unroll
+    for (int st = FIRST; st < LAST; ++st) {
+      if (st + 2 < LAST) fr[(st + 2) % 3] = rd(st + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr ((CHADA_PAIR_ABL & 4) != 0) {
+        if (st < NPV) o[st][0] += (float)fr[st % 3][0]; else sacc[(st - NPV) % 2][0] += (float)fr[st % 3][1];
+      } else if (st < NPV) {
+        o[st] = mfma16(fr[st % 3], pf, o[st]);
+      } else {
+        const int kb = (st - NPV) % 2, ks = (st - NPV) / 2;
+        sacc[kb] = (ks == 0) ? mfma16(fr[st % 3], qf[0], f32x4{0.f, 0.f, 0.f, 0.f}) : mfma16(fr[st % 3], qf[ks], sacc[kb]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  auto seg_y = [&](int kt, auto masked_tag) {   // softmax of tile kt (attn_fwd_tile's arithmetic, CB = 1).  The last tile's S^T is computed for both
+    // 16-key blocks whatever the sequence length (clamped key rows, finite): a block beyond the end exponentiates -inf to exactly the 0 that
+    // skipping it produced in attn_fwd_tile -- one MFMA stream without a branch per step
+    constexpr bool masked = decltype(masked_tag)::value;
+    if (idle) return;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      if (masked) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (kt * KVT + kb * 16 + 4 * g + r >= len) sacc[kb][r] = -INFINITY;
+      }
+      mx = fmaxf(fmaxf(mx, sacc[kb][0]), sacc[kb][1]);
+      mx = fmaxf(fmaxf(mx, sacc[kb][2]), sacc[kb][3]);
+    }
+    mx = rows_max(mx);
+    const float mn = fmaxf(m, mx * c);
+    const float alpha = __builtin_amdgcn_exp2f(m - mn);
+    m = mn;
+    float ps = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], c, -mn));
+        sacc[kb][r] = p;
+        ps += p;
+      }
+    }
+    ls = ls * alpha + ps;
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+#pragma unroll
+      for (int db = 0; db < DB; ++db) o[db] *= alpha;
+    }
+    pf = pack8(sacc[0], sacc[1]);
+  };
+  // ---- prologue: K(0), K(1) by half B, V(0) by half A; first barrier publishes them
+  if (halfB) {
+    fetch(0, sKb);
+    if (nkt > 1) fetch(1, sKb + KSLOT);
+  } else {
+    fetch(0, sVb);
+  }
+  // (the builtin, not asm: hipcc's wait insertion must KNOW that the Q fragment loads above have landed -- it does not read asm waits, is
+  // path-insensitive, and would otherwise count them down with vmcnt(11) .. vmcnt(0) in front of the S^T MFMAs of EVERY tile, draining the
+  // LDS-DMA pieces issued one segment earlier with them)
+  __builtin_amdgcn_s_waitcnt(0x0070);
+  asm volatile("s_barrier" ::: "memory");
+  if (halfB) asm volatile("s_barrier" ::: "memory");   // half B runs one segment behind
+  // X_0: S(0) only
+  seg_x(sVb, sKb, std::false_type{}, std::true_type{});
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  int kslot = 0, vslot = 0;   // element offsets of K(kt) / V(kt)
+  auto refill = [&](int kt) {   // in Y_kt: half B fetches K(kt + 2) over K(kt) (last read one segment ago: this half's X_kt), half A fetches V(kt + 1)
+    if constexpr ((CHADA_PAIR_ABL & 1) == 0) {   // into the slot of V(kt - 2) (last read by half B two segments ago)
+      if (halfB) {
+        if (kt + 2 < nkt) fetch(kt + 2, sKb + kslot);
+      } else {
+        const int vnext = (vslot == 2 * VSLOT) ? 0 : vslot + VSLOT;
+        if (kt + 1 < nkt) fetch(kt + 1, sVb + vnext);
+      }
+    }
+  };
+  for (int kt = 0; kt < nkt - 1; ++kt) {
+    // Y_kt: the refill first (it goes out while the exponentials run), then the softmax
+    refill(kt);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr ((CHADA_PAIR_ABL & 8) == 0) seg_y(kt, std::false_type{}); else pf = pack8(sacc[0], sacc[1]);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // X_{kt+1}: O += P(kt) V(kt), then S(kt + 1)
+    const int knext = KSLOT - kslot;
+    seg_x(sVb + vslot, sKb + knext, std::true_type{}, std::true_type{});
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    kslot = knext;
+    vslot = (vslot == 2 * VSLOT) ? 0 : vslot + VSLOT;
+  }
+  // the last tile: Y (masked softmax), then O += P V alone
+  if constexpr ((CHADA_PAIR_ABL & 8) == 0) seg_y(nkt - 1, std::true_type{}); else pf = pack8(sacc[0], sacc[1]);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  seg_x(sVb + vslot, sKb, std::true_type{}, std::false_type{});
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if (!halfB) asm volatile("s_barrier" ::: "memory");   // half A's trailing segment
+  if (idle) return;
+  const float lt = rows_sum(ls);
+  const float inv = 1.0f / lt;
+  store_row_blocks<DB>(out + (size_t)(seq0 + min(qrow, len - 1)) * D + h * DH, qrow < len, o, inv, g);
+  if (g == 0 && qrow < len) lse[(size_t)h * T + seq0 + qrow] = (m + log2f(lt)) * LN2;
+}
+
+// =====================================================================================
 // backward: delta[h][t] = sum_d dO[t,h,d] * O[t,h,d]
 // =====================================================================================
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
@@ -1611,6 +1811,15 @@ extern "C" int chadavit_attn_fwd(const chada_bf16* qkv_, chada_bf16* out_, float
   static const int m32_variant = getenv("CHADAVIT_ATTN_FWD_M32") ? atoi(getenv("CHADAVIT_ATTN_FWD_M32")) : 0;
   // CHADAVIT_ATTN_FWD_RM=1: the 16x16x32 forward on ROW-MAJOR stages (whole 128-byte lines per LDS-DMA instruction), dh 96 / 192 / 384
   static const int fwd_rm = getenv("CHADAVIT_ATTN_FWD_RM") ? atoi(getenv("CHADAVIT_ATTN_FWD_RM")) : 0;
+  // dh 384: the paired schedule (attn_fwd_pair_kernel: bit-identical to attn_fwd_dma_kernel<384>, 908 -> 815-821 us on cfg5's global pass);
+  // CHADAVIT_ATTN_FWD_PAIR=0 keeps the older kernel (same-box A/B, tests)
+  static const int fwd_pair = getenv("CHADAVIT_ATTN_FWD_PAIR") ? atoi(getenv("CHADAVIT_ATTN_FWD_PAIR")) : 1;
+  if (fwd_pair > 0 && fwd_rm <= 0 && dh == 384) {
+    hipLaunchKernelGGL((attn_fwd_pair_kernel<384>), dim3(n_work * H), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const bf16_t*>(qkv_),
+                       reinterpret_cast<bf16_t*>(out_), lse, cu_seqlens, work, T, D, H, 1.0f / sqrtf((float)dh));
+    CHADA_CHECK_LAUNCH();
+    return 0;
+  }
   if (fwd_rm > 0 && (dh == 96 || dh == 192 || dh == 384)) {
     const bf16_t* qkv = reinterpret_cast<const bf16_t*>(qkv_);
     bf16_t* out = reinterpret_cast<bf16_t*>(out_);

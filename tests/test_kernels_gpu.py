@@ -333,6 +333,40 @@ def test_attention_fwd_bwd(nch, p, D, H):
     _close(dqkv[:, :D], g[:, :D], 3e-2, 3e-2 * scale, "dQ")
 
 
+def test_attention_fwd_dh384_paired_schedule_is_bit_identical_to_the_one_it_replaced(tmp_path):
+    """dh 384 dispatches attn_fwd_pair_kernel (the two waves of every SIMD in complementary phases, K ring of two / V ring of three, two barriers per key
+    tile): same arithmetic in the same order as attn_fwd_dma_kernel<384> -- outputs and LSE must agree BIT FOR BIT with that kernel
+    (CHADAVIT_ATTN_FWD_PAIR=0, read once per process: child process) on ragged batches: 1961-token sequences, a last tile of one key (len 33 = 32 + 1),
+    a single tile, sequences shorter than a tile, waves without query rows."""
+    import subprocess, sys, os
+    from chadavit_amd import ops
+    from chadavit_amd.ragged import RaggedBatch
+    dev = _dev()
+    cases = [([10, 1, 3], 196), ([2, 10, 1], 36), ([1], 4), ([5, 7], 196)]
+    code = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from chadavit_amd import ops
+from chadavit_amd.ragged import RaggedBatch
+dev = torch.device("cuda:0"); outs = []
+for i, (nch, p) in enumerate(%r):
+    rb = RaggedBatch(nch, p, dev)
+    qkv = torch.randn((rb.T, 3 * 768), generator=torch.Generator(device="cpu").manual_seed(40 + i)).bfloat16().to(dev)
+    o, l = ops.attn_fwd(qkv, rb.cu_seqlens, rb.work, 2)
+    outs.append((o.cpu(), l.cpu()))
+torch.save(outs, %r)
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), cases, str(tmp_path / "old.pt"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CHADAVIT_ATTN_FWD_PAIR="0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    old = torch.load(tmp_path / "old.pt")
+    for i, (nch, p) in enumerate(cases):
+        rb = RaggedBatch(nch, p, dev)
+        qkv = torch.randn((rb.T, 3 * 768), generator=torch.Generator(device="cpu").manual_seed(40 + i)).bfloat16().to(dev)
+        o, l = ops.attn_fwd(qkv, rb.cu_seqlens, rb.work, 2)
+        assert torch.equal(o.cpu().view(torch.int16), old[i][0].view(torch.int16)) and torch.equal(l.cpu(), old[i][1]), (nch, p)
+        _close(o, _attn_ref(qkv.float(), rb.host_cu_seqlens, 2), 2e-2, 2e-2, f"paired forward {nch}")
+
+
 def test_attention_fwd_row_major_stages_and_m32_at_dh384():
     """Two forward instances that the default dispatch does not use, kept for their measurements (profiles/r05o_*): (a) the 16x16x32
     forward on ROW-MAJOR LDS stages (CHADAVIT_ATTN_FWD_RM=1: whole 128-byte lines per LDS-DMA instruction, chunks swizzled on the source side;
