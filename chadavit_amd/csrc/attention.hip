@@ -636,28 +636,33 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pair_kernel(const bf16_t* __r
     constexpr int NPV = DB, NS = 2 * KS;
     constexpr int FIRST = DO_PV ? 0 : NPV, LAST = DO_S ? NPV + NS : NPV;
 #ifndef CHADA_PAIR_ABL
-#define CHADA_PAIR_ABL 0   // ablations for timing only (wrong results): 1 = no refills, 2 = no fragment reads, 4 = no MFMAs, 8 = no softmax
+#define CHADA_PAIR_ABL 0   // ablations for timing only (wrong results): 1 = no refills, 2 = no fragment reads, 4 = no MFMAs, 8 = no softmax, 16 = V by plain reads
 #endif
     auto rd = [&](int st) {   // step st >= NPV: k-step (st - NPV) / 2 of key block (st - NPV) % 2
       if constexpr ((CHADA_PAIR_ABL & 2) != 0) return qf[st % KS];
+      if constexpr ((CHADA_PAIR_ABL & 16) != 0) { if (st < NPV) return lds_read8(sV + st * 512 + l * 8); }   // (plain 16-byte reads instead of the transpose reads)
       if (st < NPV) return lds_read_tr8(sV + st * 512, 16);
       const int kb = (st - NPV) % 2, ks = (st - NPV) / 2;
       return lds_read8(sK + (kb * KS + ks) * 512 + l * 8);
     };
-    bf16x8 fr[3];
-    fr[FIRST % 3] = rd(FIRST);
-    fr[(FIRST + 1) % 3] = rd(FIRST + 1);
+#ifndef CHADA_PAIR_PD
+#define CHADA_PAIR_PD 2
+#endif
+    constexpr int PD = CHADA_PAIR_PD, NF = PD + 1;   // fragments requested PD steps ahead of their MFMA
+    bf16x8 fr[NF];
+#pragma unroll
+    for (int i = 0; i < PD; ++i) fr[(FIRST + i) % NF] = rd(FIRST + i);
 #pragma unroll
     for (int st = FIRST; st < LAST; ++st) {
-      if (st + 2 < LAST) fr[(st + 2) % 3] = rd(st + 2);
+      if (st + PD < LAST) fr[(st + PD) % NF] = rd(st + PD);
       __builtin_amdgcn_sched_barrier(0);
       if constexpr ((CHADA_PAIR_ABL & 4) != 0) {
-        if (st < NPV) o[st][0] += (float)fr[st % 3][0]; else sacc[(st - NPV) % 2][0] += (float)fr[st % 3][1];
+        if (st < NPV) o[st][0] += (float)fr[st % NF][0]; else sacc[(st - NPV) % 2][0] += (float)fr[st % NF][1];
       } else if (st < NPV) {
-        o[st] = mfma16(fr[st % 3], pf, o[st]);
+        o[st] = mfma16(fr[st % NF], pf, o[st]);
       } else {
         const int kb = (st - NPV) % 2, ks = (st - NPV) / 2;
-        sacc[kb] = (ks == 0) ? mfma16(fr[st % 3], qf[0], f32x4{0.f, 0.f, 0.f, 0.f}) : mfma16(fr[st % 3], qf[ks], sacc[kb]);
+        sacc[kb] = (ks == 0) ? mfma16(fr[st % NF], qf[0], f32x4{0.f, 0.f, 0.f, 0.f}) : mfma16(fr[st % NF], qf[ks], sacc[kb]);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
