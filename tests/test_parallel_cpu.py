@@ -261,6 +261,36 @@ def test_bench_mixed_channel_batches_are_token_balanced_across_ranks():
         assert max(naive) / min(naive) - 1.0 > 0.02  # what the sampler is there to avoid
 
 
+def test_bench_power_sampler_reads_the_gpus_own_hwmon_and_degrades_to_none(tmp_path, monkeypatch):
+    """bench.py's `power` object: board power / shader clock of THIS rank's GPU from the hwmon directory of its PCI function, sampled from a thread over
+    the timed steps -- and simply absent (no exception, no key) where sysfs does not expose it."""
+    import glob as _glob
+    import time
+    import types
+    import bench
+    hw = tmp_path / "hwmon7"
+    hw.mkdir()
+    (hw / "power1_input").write_text("1370000000\n")
+    (hw / "freq1_input").write_text("1938000000\n")
+    (hw / "power1_cap").write_text("1400000000\n")
+    seen = []
+    monkeypatch.setattr(_glob, "glob", lambda pat: (seen.append(pat), [str(hw)])[1])
+    props = types.SimpleNamespace(pci_domain_id=0, pci_bus_id=0x75, pci_device_id=0)
+    fake = types.SimpleNamespace(cuda=types.SimpleNamespace(get_device_properties=lambda dev: props))
+    ps = bench.PowerSampler(fake, 0)
+    assert seen == ["/sys/bus/pci/devices/0000:75:00.0/hwmon/hwmon*"] and ps.idle == (1370.0, 1938.0)
+    ps.start()
+    time.sleep(0.15)
+    out = ps.stop()
+    assert out["board_w"] == 1370.0 and out["sclk_mhz"] == 1938.0 and out["cap_w"] == 1400.0 and out["samples"] >= 2
+    monkeypatch.setattr(_glob, "glob", lambda pat: [])
+    ps = bench.PowerSampler(fake, 0)
+    ps.start()
+    assert ps.dir is None and ps.idle is None and ps.stop() is None
+    broken = types.SimpleNamespace(cuda=types.SimpleNamespace(get_device_properties=lambda dev: (_ for _ in ()).throw(RuntimeError("no device"))))
+    assert bench.PowerSampler(broken, 0).stop() is None
+
+
 def test_ragged_batch_cache_returns_the_same_description():
     from chadavit_amd.ragged import _CACHE, _CACHE_MAX, ragged_batch
     dev = torch.device("cpu")
