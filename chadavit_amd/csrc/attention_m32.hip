@@ -1,4 +1,4 @@
-// Variable-length flash attention forward on v_mfma_f32_32x32x16_bf16 (gfx950), head widths 96 and 192 (and 384 as an instance that is not dispatched).
+// Variable-length flash attention forward on v_mfma_f32_32x32x16_bf16 (gfx950), head widths 96 and 192.
 // replaces chada_vit.py:105-111 (nn.MultiheadAttention + key padding mask), forward.
 //
 // What differs from attention.hip's 16x16x32 forward, and why (measurements: profiles/r03a_coissue*.txt, r03b_attention_fwd.md):
@@ -114,7 +114,6 @@ __device__ __forceinline__ void fwd_tile(BufRsrc qb, bf16_t* __restrict__ dst, c
   using C = Cfg<DH, CB, NW>;
   constexpr int KS = C::KS, DB = C::DB, KB = C::KB, KP = C::KP, KVT = C::KVT, NKR = C::NKR, NRW = C::NRW;
   const int hi = l >> 5;
-  // (dh 384, one wave per SIMD: the next tile's 12 pieces dealt out between the S^T MFMAs instead of this burst measured +2.6 %: 916 against 892 us)
   if (issue) {
 #pragma unroll
     for (int i = 0; i < NRW; ++i) {
@@ -133,24 +132,6 @@ __device__ __forceinline__ void fwd_tile(BufRsrc qb, bf16_t* __restrict__ dst, c
   // register ring, as attention.hip does, costs this kernel its third wave per SIMD at dh = 96 -- 168 registers -- and measured
   // slower: 472 against ~380 us; hipcc's own placement stays.)
   f32x16 s[CB][KB];
-  constexpr bool RING = DH > 192;   // dh 384 (one wave per SIMD, 288 registers of O / Q state): fragments requested two steps ahead through a
-                                    // ring of three, pinned -- left alone hipcc hoists all 24 + 24 fragment reads of a tile and spills 380 registers
-  if constexpr (RING) {
-    static_assert(!RING || (CB == 1 && KB == 1), "ring path: one 32-key block, one query block per wave");
-    bf16x8 kr[3];
-    kr[0] = lds_read8(sK + l * 8);
-    kr[1] = lds_read8(sK + 512 + l * 8);
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      if (ks + 2 < KS) kr[(ks + 2) % 3] = lds_read8(sK + (ks + 2) * 512 + l * 8);
-      __builtin_amdgcn_sched_barrier(0);
-      if (ks == 0)
-        s[0][0] = mfma32(kr[0], qf[0][0], MODE == 2 ? minit[0] : splat16(0.f));
-      else
-        s[0][0] = mfma32(kr[ks % 3], qf[0][ks], s[0][0]);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  } else {
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) {
     if (MASKED && kb >= nkb) continue;
@@ -165,7 +146,6 @@ __device__ __forceinline__ void fwd_tile(BufRsrc qb, bf16_t* __restrict__ dst, c
           s[cb][kb] = mfma32(kf, qf[cb][ks], s[cb][kb]);
       }
     }
-  }
   }
   // ---- softmax
 #pragma unroll
@@ -240,37 +220,6 @@ __device__ __forceinline__ void fwd_tile(BufRsrc qb, bf16_t* __restrict__ dst, c
     }
   }
   // ---- O^T += V^T P^T: P of k-step kp = registers 8 (kp & 1) .. +7 of the 32-key block kp >> 1, already in B-operand order
-  if constexpr (RING) {
-    bf16x8 pf[KP];
-#pragma unroll
-    for (int kp = 0; kp < KP; ++kp) {
-      const f32x16& sv = s[0][kp >> 1];
-      const int b0 = 8 * (kp & 1);
-      pf[kp] = pack8f(sv[b0], sv[b0 + 1], sv[b0 + 2], sv[b0 + 3], sv[b0 + 4], sv[b0 + 5], sv[b0 + 6], sv[b0 + 7]);
-    }
-    const int g = l >> 4, ii = l & 15;
-    const bf16_t* vrow = sV + (4 * (g >> 1) + (ii >> 2)) * 32 + (g & 1) * 16 + (ii & 3) * 4;
-    constexpr int NP = KP * DB;
-    bf16x4 vr[3][2];
-    auto rd = [&](int st, bf16x4 (&v)[2]) {   // step st = (kp, db) = (st / DB, st % DB): record kp * DB + db
-      v[0] = lds_read_tr4(vrow + st * 512);
-      v[1] = lds_read_tr4(vrow + st * 512 + 8 * 32);
-    };
-    rd(0, vr[0]);
-    rd(1, vr[1]);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int st = 0; st < NP; ++st) {
-      const int kp = st / DB, db = st % DB;
-      if (st + 2 < NP) rd(st + 2, vr[(st + 2) % 3]);
-      __builtin_amdgcn_sched_barrier(0);
-      if (!MASKED || kp < nkp) {
-        const bf16x8 vf = __builtin_shufflevector(vr[st % 3][0], vr[st % 3][1], 0, 1, 2, 3, 4, 5, 6, 7);
-        o[0][db] = mfma32(vf, pf[kp], o[0][db]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  } else
 #pragma unroll
   for (int kp = 0; kp < KP; ++kp) {
     if (MASKED && kp >= nkp) continue;
@@ -339,7 +288,7 @@ __device__ __forceinline__ void fwd_item(BufRsrc qrs, bf16_t* smem, int len, int
 }
 
 template <int DH, int CB, int NW, int LEAN>
-__global__ __launch_bounds__(64 * NW, (CB > 1 || DH > 192 ? 1 : (DH <= 96 ? (KV32_AT_DH96 ? 4 : 3) : 2))) void attn_fwd_m32_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(64 * NW, (CB > 1 ? 1 : (DH <= 96 ? (KV32_AT_DH96 ? 4 : 3) : 2))) void attn_fwd_m32_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                                                     float* __restrict__ lse, const int* __restrict__ cu,
                                                                                     const int* __restrict__ work, int T, int D, int H,
                                                                                     float scale) {
@@ -474,10 +423,6 @@ extern "C" int chadavit_attn_fwd_m32(const chada_bf16* qkv_, chada_bf16* out_, f
     if (lean == 0) M32_LAUNCH(192, 1, 4, 0);
     else if (lean == 1) M32_LAUNCH(192, 1, 4, 1);
     else M32_LAUNCH(192, 1, 4, 2);
-  } else if (dh == 384) {  // one wave per SIMD (192 accumulator + 96 Q registers per wave).  Same speed as attn_fwd_dma_kernel<384> on the global
-                           // pass (892 against 895-922 us by box), 5-10 % faster on ragged and local-crop batches; not the default dispatch
-    if (lean == 0) M32_LAUNCH(384, 1, 4, 0);
-    else M32_LAUNCH(384, 1, 4, 2);
   } else {
     return 2;
   }

@@ -1,4 +1,4 @@
-"""attn_fwd_m32_kernel<384> (32x32x16, 4 waves x 32 query rows, one wave per SIMD) against the dispatched attn_fwd_dma_kernel<384> (16x16x32, 8 x 16 rows):
+"""(needs scratch/r5/attention_m32_dh384_instance.patch applied) attn_fwd_m32_kernel<384> (32x32x16, 4 waves x 32 query rows, one wave per SIMD) against the dispatched attn_fwd_dma_kernel<384> (16x16x32, 8 x 16 rows):
 results and time at cfg5's global pass (64 x 1961 tokens, 2 heads of 384) and a ragged mix."""
 import ctypes, sys, torch, random
 sys.path.insert(0, '.')
