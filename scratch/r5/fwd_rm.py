@@ -29,7 +29,7 @@ for name, nch, p, D, H in (("cfg2 global 1024", [3] * 2048, 196, 192, 2), ("cfg2
     o1 = torch.empty_like(o0); l1 = torch.empty_like(l0)
     rc = lib().chadavit_attn_fwd_m32(ops._ptr(qkv), ops._ptr(o1), ops._ptr(l1), ops._ptr(rb.cu_seqlens), ops._ptr(rb.work), ctypes.c_int(rb.n_work),
                                      ctypes.c_int(rb.T), ctypes.c_int(D), ctypes.c_int(H), ctypes.c_int(1), ops._stream())
-    assert rc == 0, rc
+    assert rc == 0 or D == 768, rc   # (the 32x32x16 kernel has no dh 384 instance in the library: the difference columns are meaningless there)
     torch.cuda.synchronize()
     print(f"{tag:8s} {name:18s} T={rb.T:8d}: max |o - o_m32| {float((o1.float() - o0.float()).abs().max()):.4f}  max |lse diff| {float((l1 - l0).abs().max()):.2e}   "
           f"attn_fwd {t(lambda: ops.attn_fwd(qkv, rb.cu_seqlens, rb.work, H, out=o0, lse=l0)):8.1f} us", flush=True)
