@@ -1370,25 +1370,27 @@ __global__ __launch_bounds__(256, (DH > 192 ? 1 : 2)) void attn_bwd_dkv_dma_kern
 // the source side (dkv_swz: K is read both row-wise and transposed), one barrier per key tile, no staging registers; LDS
 // reads one / two groups ahead of the MFMAs.  Same arithmetic as attn_bwd_dq_kernel, bit-identical results.
 // =====================================================================================
-template <int DH, int CB, bool MASKED>
+template <int DH, int CB, bool MASKED, int NW = 4>
 __device__ __forceinline__ void attn_dq_tile(BufRsrc kg, BufRsrc vg, bf16_t* __restrict__ dst, const bf16_t* __restrict__ rd,
                                              bool issue, bool idle, int kt, int len, unsigned ldq, float c, int w, int l,
-                                             const int (&rec_row)[(DH > 96 ? 32 : 64) * (DH / 8) / 256],
-                                             const int (&rec_col)[(DH > 96 ? 32 : 64) * (DH / 8) / 256],
+                                             const int (&rec_row)[(DH > 96 ? 32 : 64) * (DH / 8) / (64 * NW)],
+                                             const int (&rec_col)[(DH > 96 ? 32 : 64) * (DH / 8) / (64 * NW)],
                                              const bf16x8 (&qf)[CB][DH / 32], const bf16x8 (&dof)[CB][DH / 32],
                                              const float (&L2)[CB], const float (&dl)[CB], f32x4 (&dq)[CB][DH / 16]) {
   constexpr int KS = DH / 32, DB = DH / 16;
   constexpr int KVT = (DH > 96) ? 32 : 64, K2 = KVT / 32;
-  constexpr int NRW = KVT * (DH / 8) / 256;
+  constexpr int NRW = KVT * (DH / 8) / (64 * NW);
   constexpr int TILE_E = KVT * DH;
-  const int g = l >> 4, li = l & 15;
+  const int g = l >> 4;
+  int li = l & 15;
+  if constexpr (NW == 8) asm volatile("" : "+v"(li));   // (dh 384, 192 registers of Q / dO / dQ state: keeps the tile's swizzled fragment addresses from being hoisted out of the tile loop)
   if (issue) {
     const int r0 = (kt + 1) * KVT;
 #pragma unroll
     for (int i = 0; i < NRW; ++i) {
       const unsigned row = (unsigned)min(r0 + rec_row[i], len - 1);
-      lds_dma16(kg, dst + (w + 4 * i) * 512, (row * ldq + rec_col[i]) * 2, 0);
-      lds_dma16(vg, dst + TILE_E + (w + 4 * i) * 512, (row * ldq + rec_col[i]) * 2, 0);
+      lds_dma16(kg, dst + (w + NW * i) * 512, (row * ldq + rec_col[i]) * 2, 0);
+      lds_dma16(vg, dst + TILE_E + (w + NW * i) * 512, (row * ldq + rec_col[i]) * 2, 0);
     }
   }
   __builtin_amdgcn_sched_barrier(0);  // the DMA goes out FIRST: free of the alias edge, the scheduler would sink it below the math
@@ -1474,26 +1476,27 @@ __device__ __forceinline__ void attn_dq_tile(BufRsrc kg, BufRsrc vg, bf16_t* __r
 // One 16-row query block per wave (CB = 1: dh 192, where two spill) fits three blocks per CU: 175 registers at two waves per SIMD, 168 with 4
 // spilled outside the loop at three -- and the third wave is worth 6 %: 1 017 -> 957 us on cfg3's global pass, 257 -> 241 us on its local
 // one (same box, interleaved; profiles/r05g_dq192_three_blocks_per_cu.log).
-template <int DH, int CB, bool FUSE_DELTA>
-__global__ __launch_bounds__(256, (CB == 1 && DH <= 192 ? 3 : 2)) void attn_bwd_dq_dma_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+template <int DH, int CB, bool FUSE_DELTA, int NW = 4>
+__global__ __launch_bounds__(64 * NW, (CB == 1 && DH <= 192 ? 3 : (NW == 8 ? 1 : 2))) void attn_bwd_dq_dma_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                           const float* __restrict__ lse, float* __restrict__ delta,
                                                           bf16_t* __restrict__ dqkv, const int* __restrict__ cu,
                                                           const int* __restrict__ work, int T, int D, int H, float scale,
                                                           const bf16_t* __restrict__ out) {
   constexpr int KS = DH / 32, DB = DH / 16;
   constexpr int KVT = (DH > 96) ? 32 : 64;
-  constexpr int NRW = KVT * (DH / 8) / 256;  // 1 KiB records per wave and tensor
+  constexpr int NRW = KVT * (DH / 8) / (64 * NW);  // 1 KiB records per wave and tensor
   constexpr int STAGE = 2 * KVT * DH;        // K tile | V tile, row-major, swizzled on the DMA source side (see dkv_swz)
+  constexpr int QPB = NW * 16 * CB;          // query rows per block
   __shared__ __attribute__((aligned(16))) bf16_t smem[2 * STAGE];
 
   const int tid = threadIdx.x, l = tid & 63, g = l >> 4, li = l & 15;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  constexpr int SPLIT = 2 / CB;
+  constexpr int SPLIT = TILE / QPB;
   const WorkItem it = decode_work<SPLIT>(work, H);
   const int b = it.b, qt = it.t, h = it.h, part = it.part;
   if (b < 0) return;
   const int seq0 = cu[b], len = cu[b + 1] - seq0;
-  if (qt * TILE + part * 64 * CB >= len) return;
+  if (qt * TILE + part * QPB >= len) return;
   const size_t ld = 3 * (size_t)D;
   const bf16_t* qbase = qkv + (size_t)seq0 * ld + h * DH;
   const bf16_t* kbase = qbase + D;
@@ -1505,7 +1508,7 @@ __global__ __launch_bounds__(256, (CB == 1 && DH <= 192 ? 3 : 2)) void attn_bwd_
   int qrow[CB];
 #pragma unroll
   for (int cb = 0; cb < CB; ++cb) {
-    qrow[cb] = qt * TILE + part * 64 * CB + w * 16 * CB + cb * 16 + li;
+    qrow[cb] = qt * TILE + part * QPB + w * 16 * CB + cb * 16 + li;
     const int qr = min(qrow[cb], len - 1);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -1536,30 +1539,30 @@ __global__ __launch_bounds__(256, (CB == 1 && DH <= 192 ? 3 : 2)) void attn_bwd_
   int rec_row[NRW], rec_col[NRW];
 #pragma unroll
   for (int i = 0; i < NRW; ++i) {
-    const int id = (w + 4 * i) * 64 + l, row = id / (DH / 8), ch = id % (DH / 8);
+    const int id = (w + NW * i) * 64 + l, row = id / (DH / 8), ch = id % (DH / 8);
     rec_row[i] = row;
     rec_col[i] = (ch ^ dkv_swz<DH>(row)) * 8;
   }
   const unsigned ldq = 3u * (unsigned)D;
   const int nkt = (len + KVT - 1) / KVT;
   const BufRsrc krs = make_rsrc(kbase), vrs = make_rsrc(vbase);
-  const bool idle = qt * TILE + part * 64 * CB + w * 16 * CB >= len;  // no valid query row in this wave
+  const bool idle = qt * TILE + part * QPB + w * 16 * CB >= len;  // no valid query row in this wave
   // tile 0 (no LDS read follows before the first barrier: issued bare)
 #pragma unroll
   for (int i = 0; i < NRW; ++i) {
     const unsigned row = (unsigned)min(rec_row[i], len - 1);
-    lds_dma16(krs, smem + (w + 4 * i) * 512, (row * ldq + rec_col[i]) * 2, 0);
-    lds_dma16(vrs, smem + KVT * DH + (w + 4 * i) * 512, (row * ldq + rec_col[i]) * 2, 0);
+    lds_dma16(krs, smem + (w + NW * i) * 512, (row * ldq + rec_col[i]) * 2, 0);
+    lds_dma16(vrs, smem + KVT * DH + (w + NW * i) * 512, (row * ldq + rec_col[i]) * 2, 0);
   }
   for (int kt = 0; kt < nkt - 1; ++kt) {
     // tile kt has landed (LDS-DMA completion is visible only through the issuing wave's vmcnt) and everybody is done
     // reading the other stage
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    attn_dq_tile<DH, CB, false>(krs, vrs, smem + ((kt + 1) & 1) * STAGE, smem + (kt & 1) * STAGE, true, idle, kt, len, ldq, c, w, l, rec_row,
+    attn_dq_tile<DH, CB, false, NW>(krs, vrs, smem + ((kt + 1) & 1) * STAGE, smem + (kt & 1) * STAGE, true, idle, kt, len, ldq, c, w, l, rec_row,
                                 rec_col, qf, dof, L2, dl, dq);
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  attn_dq_tile<DH, CB, true>(krs, vrs, smem + (nkt & 1) * STAGE, smem + ((nkt - 1) & 1) * STAGE, false, idle, nkt - 1, len, ldq, c, w, l,
+  attn_dq_tile<DH, CB, true, NW>(krs, vrs, smem + (nkt & 1) * STAGE, smem + ((nkt - 1) & 1) * STAGE, false, idle, nkt - 1, len, ldq, c, w, l,
                              rec_row, rec_col, qf, dof, L2, dl, dq);
 #pragma unroll
   for (int cb = 0; cb < CB; ++cb) {
@@ -1927,9 +1930,17 @@ static int attn_bwd_launch(const chada_bf16* qkv_, const chada_bf16* out_, const
       if (parts & 4)
         hipLaunchKernelGGL((attn_bwd_dkv_dma_kernel<192, 1>), dim3(2 * n_work * H), blk, 0, s, qkv, dout, lse, delta, dqkv, cu_seqlens, work, T, D, H, scale);
       break;
-    case 384:  // dQ: eight waves x 16 query rows, fragment-major K / V / K^T stages; dK/dV: one wave per SIMD (288 registers of state)
-      if ((parts & 2) && fuse_delta)
+    case 384:  // dQ: eight waves x 16 query rows on row-major K / V stages; dK/dV: one wave per SIMD (288 registers of state)
+      if ((parts & 2) && fuse_delta) {
+        // the row-major-stage kernel as eight waves x 16 rows (round 5: K fetched ONCE per tile and in whole 128-byte lines -- 48 KiB per tile instead of
+        // the fragment-major kernel's 72, 96 KiB of LDS instead of 144; bit-identical; 1 261 -> 1 188 us on cfg5's global pass, ragged 939 -> 866).
+        // CHADAVIT_ATTN_DQ_RM=0 keeps attn_bwd_dq_fm_kernel (same-box A/B, tests)
+        static const int dq_rm = getenv("CHADAVIT_ATTN_DQ_RM") ? atoi(getenv("CHADAVIT_ATTN_DQ_RM")) : 1;
+        if (dq_rm > 0)
+          hipLaunchKernelGGL((attn_bwd_dq_dma_kernel<384, 1, true, 8>), dim3(n_work * H), dim3(512), 0, s, qkv, dout, lse, delta, dqkv, cu_seqlens, work, T, D, H, scale, out);
+        else
         hipLaunchKernelGGL((attn_bwd_dq_fm_kernel<384, 1>), dim3(n_work * H), dim3(512), 0, s, qkv, dout, lse, delta, dqkv, cu_seqlens, work, T, D, H, scale, out);
+      }
       else if (parts & 2)   // (the fragment-major kernel always derives delta: the register-staged one serves the two-stream form)
         hipLaunchKernelGGL((attn_bwd_dq_kernel<384, 1, false>), dim3(n_work * 2 * H), blk, 0, s, qkv, dout, lse, delta, dqkv, cu_seqlens, work, T, D, H, scale, out);
       if (parts & 4)

@@ -333,7 +333,7 @@ def test_attention_fwd_bwd(nch, p, D, H):
     _close(dqkv[:, :D], g[:, :D], 3e-2, 3e-2 * scale, "dQ")
 
 
-def test_attention_fwd_dh384_paired_schedule_is_bit_identical_to_the_one_it_replaced(tmp_path):
+def test_attention_dh384_round5_kernels_are_bit_identical_to_the_ones_they_replaced(tmp_path):
     """dh 384 dispatches attn_fwd_pair_kernel (the two waves of every SIMD in complementary phases, K ring of two / V ring of three, two barriers per key
     tile): same arithmetic in the same order as attn_fwd_dma_kernel<384> -- outputs and LSE must agree BIT FOR BIT with that kernel
     (CHADAVIT_ATTN_FWD_PAIR=0, read once per process: child process) on ragged batches: 1961-token sequences, a last tile of one key (len 33 = 32 + 1),
@@ -353,10 +353,14 @@ for i, (nch, p) in enumerate(%r):
     rb = RaggedBatch(nch, p, dev)
     qkv = torch.randn((rb.T, 3 * 768), generator=torch.Generator(device="cpu").manual_seed(40 + i)).bfloat16().to(dev)
     o, l = ops.attn_fwd(qkv, rb.cu_seqlens, rb.work, 2)
-    outs.append((o.cpu(), l.cpu()))
+    do = torch.randn((rb.T, 768), generator=torch.Generator(device="cpu").manual_seed(80 + i)).bfloat16().to(dev)
+    delta = torch.empty((2, rb.T), device=dev)
+    dqkv = ops.attn_bwd(qkv, o, do, l, rb.cu_seqlens, rb.work, 2, delta=delta)
+    outs.append((o.cpu(), l.cpu(), dqkv.cpu(), delta.cpu()))
 torch.save(outs, %r)
 """ % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), cases, str(tmp_path / "old.pt"))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CHADAVIT_ATTN_FWD_PAIR="0"), capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CHADAVIT_ATTN_FWD_PAIR="0", CHADAVIT_ATTN_DQ_RM="0"), capture_output=True, text=True,
+                       timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     old = torch.load(tmp_path / "old.pt")
     for i, (nch, p) in enumerate(cases):
@@ -365,6 +369,11 @@ torch.save(outs, %r)
         o, l = ops.attn_fwd(qkv, rb.cu_seqlens, rb.work, 2)
         assert torch.equal(o.cpu().view(torch.int16), old[i][0].view(torch.int16)) and torch.equal(l.cpu(), old[i][1]), (nch, p)
         _close(o, _attn_ref(qkv.float(), rb.host_cu_seqlens, 2), 2e-2, 2e-2, f"paired forward {nch}")
+        # dQ at dh 384: the row-major-stage kernel as eight waves x 16 rows against the fragment-major one it replaced (dK / dV: same kernel in both)
+        do = torch.randn((rb.T, 768), generator=torch.Generator(device="cpu").manual_seed(80 + i)).bfloat16().to(dev)
+        delta = torch.empty((2, rb.T), device=dev)
+        dqkv = ops.attn_bwd(qkv, o, do, l, rb.cu_seqlens, rb.work, 2, delta=delta)
+        assert torch.equal(dqkv.cpu().view(torch.int16), old[i][2].view(torch.int16)) and torch.equal(delta.cpu(), old[i][3]), (nch, p)
 
 
 def test_attention_fwd_row_major_stages():
