@@ -1202,19 +1202,28 @@ __device__ __forceinline__ void attn_dkv_tile(BufRsrc qg, BufRsrc dog, BufRsrc l
   // last query tile of the sequence: only the 16-row blocks that hold a valid query are multiplied -- wave-uniform
   // branches, identical results (the skipped blocks' P and dS are 0)
   const int nvq = MASKED ? min(KVT / 16, (len - q0 * KVT + 15) >> 4) : KVT / 16;
-  bf16x8 qfr[2], dofr[2], dot[2], qtf[2];
-  row_read(0, qfr[0], dofr[0]);
+  // fragments are requested RD steps ahead of their MFMAs through rings of RD + 1 (RD = 1: the schedule of rounds 2-4, kept at dh 96 / 192).  dh 384
+  // runs one wave per SIMD -- nobody else covers an LDS round trip -- and has the registers: four steps ahead, 1 802 -> 1 755 us on cfg5's global pass,
+  // bit-identical (2 and 3: 1 778 / 1 773)
+#ifndef CHADA_DKV_RD384
+#define CHADA_DKV_RD384 4
+#endif
+  constexpr int RD = (DH > 192) ? CHADA_DKV_RD384 : 1, R = RD + 1;
+  static_assert(RD >= 1 && RD <= DB && RD <= 2 * KS, "look-ahead within a phase");
+  bf16x8 qfr[R], dofr[R], dot[R], qtf[R];
+#pragma unroll
+  for (int i = 0; i < RD; ++i) row_read(i, qfr[i], dofr[i]);
 #pragma unroll
   for (int k2 = 0; k2 < K2; ++k2) {
     f32x4 s[CBK][2], dp[CBK][2];
 #pragma unroll
     for (int st = 0; st < 2 * KS; ++st) {
-      const int q2 = st / KS, ks = st % KS, cur = st & 1;
+      const int q2 = st / KS, ks = st % KS, cur = st % R, nxt = st + RD;
       if constexpr (SPREAD) {   // one piece per step of the first half instead of a burst behind the barrier
         if (issue && k2 == 0 && st <= NRW) issue_piece(st);
       }
-      if (st + 1 < 2 * KS) row_read(k2 * 2 * KS + st + 1, qfr[cur ^ 1], dofr[cur ^ 1]);
-      else tr_read(k2, 0, dot[0], qtf[0]);  // first transposed pair: lands under the softmax
+      if (nxt < 2 * KS) row_read(k2 * 2 * KS + nxt, qfr[nxt % R], dofr[nxt % R]);
+      else tr_read(k2, nxt - 2 * KS, dot[(nxt - 2 * KS) % R], qtf[(nxt - 2 * KS) % R]);  // first transposed pairs: land under the softmax
       __builtin_amdgcn_sched_barrier(0);
       if (!MASKED || 2 * k2 + q2 < nvq) {
 #pragma unroll
@@ -1257,9 +1266,9 @@ __device__ __forceinline__ void attn_dkv_tile(BufRsrc qg, BufRsrc dog, BufRsrc l
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int db = 0; db < DB; ++db) {
-      const int cur = db & 1;
-      if (db + 1 < DB) tr_read(k2, db + 1, dot[cur ^ 1], qtf[cur ^ 1]);
-      else if (k2 + 1 < K2) row_read((k2 + 1) * 2 * KS, qfr[0], dofr[0]);  // first row pair of the next half
+      const int cur = db % R, nxt = db + RD;
+      if (nxt < DB) tr_read(k2, nxt, dot[nxt % R], qtf[nxt % R]);
+      else if (k2 + 1 < K2) row_read((k2 + 1) * 2 * KS + (nxt - DB), qfr[(nxt - DB) % R], dofr[(nxt - DB) % R]);  // first row pairs of the next half
       __builtin_amdgcn_sched_barrier(0);
       if (!MASKED || 2 * k2 < nvq) {
 #pragma unroll
