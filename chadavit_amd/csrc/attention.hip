@@ -1208,7 +1208,10 @@ __device__ __forceinline__ void attn_dkv_tile(BufRsrc qg, BufRsrc dog, BufRsrc l
 #ifndef CHADA_DKV_RD384
 #define CHADA_DKV_RD384 4
 #endif
-  constexpr int RD = (DH > 192) ? CHADA_DKV_RD384 : 1, R = RD + 1;
+#ifndef CHADA_DKV_RD
+#define CHADA_DKV_RD 1
+#endif
+  constexpr int RD = (DH > 192) ? CHADA_DKV_RD384 : CHADA_DKV_RD, R = RD + 1;
   static_assert(RD >= 1 && RD <= DB && RD <= 2 * KS, "look-ahead within a phase");
   bf16x8 qfr[R], dofr[R], dot[R], qtf[R];
 #pragma unroll
