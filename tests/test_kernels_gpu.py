@@ -342,7 +342,8 @@ def test_attention_dh384_round5_kernels_are_bit_identical_to_the_ones_they_repla
     from chadavit_amd import ops
     from chadavit_amd.ragged import RaggedBatch
     dev = _dev()
-    cases = [([10, 1, 3], 196), ([2, 10, 1], 36), ([1], 4), ([5, 7], 196)]
+    cases = [([10, 1, 3], 196), ([2, 10, 1], 36), ([1], 4), ([5, 7], 196), ([3, 7, 1, 10, 2, 5], 7), ([1, 2, 3, 4, 5, 6, 7, 8, 9, 10], 33), ([10, 9, 1], 121),
+             ([4, 8, 2], 64)]   # (lengths 8 ... 1961: every parity of the tile count, remainders 1 ... 32; scratch/r5/pair_sweep.py runs 18 more sets)
     code = r"""
 import sys, torch
 sys.path.insert(0, %r)
