@@ -721,11 +721,14 @@ def other_workload_leg(name, args, dev, steps=3, warmup=2, graph=False, batch=No
     for i in range(warmup):
         step_fn(batch, i)
     torch.cuda.synchronize()
+    power = PowerSampler(torch, dev)
+    power.start()
     t0 = time.perf_counter()
     for i in range(steps):
         last = step_fn(batch, warmup + i)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    pw = power.stop()
     if graph:
         step_fn.close()
     res = {"workload": wl["desc"], "images_per_gpu": wl["batch"], "images_per_s": round(wl["batch"] * steps / dt, 2),
@@ -739,6 +742,8 @@ def other_workload_leg(name, args, dev, steps=3, warmup=2, graph=False, batch=No
     if wl.get("standard"):
         res["algorithmic_gflop_per_image"] = round(gflop_per_image(chans, wl["D"], wl["P"], wl["n_global"], wl["n_local"], standard=True), 1)
     res["mfma_fraction_whole_step"] = round(res["images_per_s"] * gf_exec / 1e3 / PEAK_BF16_TFLOPS, 4)
+    if pw is not None:   # which legs run at the package power cap and which do not (Base's dh 384 attention leaves cfg5 under it)
+        res["board_w"], res["sclk_mhz"] = pw["board_w"], pw["sclk_mhz"]
     if not args.no_launch_profile and not graph:
         summ = launch_profile(tr, batch, warmup + steps, nch, wl, dev, 0, in_step_steps=1)
         roof, _ = roofline_object(summ, model, nch, wl)
