@@ -27,6 +27,7 @@
 // 64 query rows per wave at one wave per SIMD, and a software-pipelined body (S'(t+1) MFMAs interleaved with the exponentials of
 // tile t, P V MFMAs with those of tile t+1, fragments two steps ahead, K / V in separate rings) at two waves per SIMD.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -397,6 +398,328 @@ __global__ __launch_bounds__(64 * NW, (CB > 1 ? 1 : (DH <= 96 ? (KV32_AT_DH96 ? 
   }
 }
 
+// =====================================================================================
+// The paired ("ping-pong") schedule on 32x32x16 bodies, head widths 96 and 192 with the factory's TWO heads (round 6).
+//
+// One 512-thread block per (image, 128-row query tile): half A (waves 0-3) runs head 0, half B (waves 4-7) head 1 of the same 128 query rows
+// -- wave w and w + 4 share a SIMD.  Both halves run the program of attn_fwd_m32_kernel<DH, 1, 4, 2> (same fragments, same order of operations:
+// results bit-identical to it), cut into two segments per key tile and held ONE SEGMENT APART by the block's barriers:
+//   X_t (matrix):          O += P(t-1) V(t-1)   then   S(t) = K(t) Q^T      -- 24 MFMAs of 32 cycles and their fragment reads, nothing else
+//   Y_t (everything else): the LDS-DMA requests for K(t+2) and V(t+1), then the softmax of S(t) -> P(t)
+// so that beside every matrix segment on a SIMD sits the partner wave's softmax / DMA segment (the three independent blocks per CU of the
+// unpaired kernel leave that to chance: MFMA busy 0.42-0.45).  The halves share no data: each owns a ring of two K tiles and two V tiles (48 KiB;
+// K(t+2) replaces K(t), last read in this half's X_t; V(t+1) replaces V(t-1), last read in X_t), a wave waits for its own pieces at the end of
+// its next X segment, the barrier behind it publishes them.  The last key tile multiplies only the 32-key blocks that hold a valid key (block-
+// uniform choice between two straight-line segment bodies, no branch inside an MFMA stream); its masked scores are -inf -> P = 0 exactly.
+// A row that leaves the fixed-reference softmax's range re-runs its half with attn_fwd_m32_kernel's own textbook loop (fwd_item<.., 0>) while
+// the other half keeps the barrier count.
+// =====================================================================================
+#ifndef CHADA_P32_PD
+#define CHADA_P32_PD 2      // fragments requested this many steps ahead of their MFMA
+#endif
+#ifndef CHADA_P32_PRIO
+#define CHADA_P32_PRIO 0    // 1: s_setprio 1 for the second-dispatched half (the guide's static form)
+#endif
+#ifndef CHADA_P32_RERUN
+#define CHADA_P32_RERUN 1   // 0 (timing only): no range check of the lean softmax
+#endif
+#ifndef CHADA_P32_ABL
+#define CHADA_P32_ABL 0     // timing-only ablations (wrong results): 1 = no refills, 2 = no fragment reads, 4 = no MFMAs, 8 = no softmax
+#endif
+template <int DH>
+__global__ __launch_bounds__(512, 1) void attn_fwd_pair32_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse,
+                                                                 const int* __restrict__ cu, const int* __restrict__ work, int T, int D,
+                                                                 float scale) {
+  using C = Cfg<DH, 1, 4>;
+  constexpr int KS = C::KS, DB = C::DB, KB = C::KB, KP = C::KP, KVT = C::KVT, NKR = C::NKR, NVR = C::NVR;
+  constexpr int KSLOT = NKR * 512, VSLOT = NVR * 512, HALF = 2 * KSLOT + 2 * VSLOT;   // bf16 elements
+  static_assert(HALF == 2 * C::STAGE, "a half's rings are also the two stages of the unpaired loop (the re-run path)");
+  static_assert(NKR % 4 == 0 && NVR % 4 == 0, "K and V records split evenly over the four waves of a half");
+  constexpr int NKW = NKR / 4, NVW = NVR / 4;   // pieces per wave and tile
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * HALF];
+
+  const int tid = threadIdx.x, l = tid & 63, hi = l >> 5, li = l & 31;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = w >> 2, wq = w & 3;
+  const int b = work[2 * blockIdx.x], qt = work[2 * blockIdx.x + 1];   // block i runs on XCD i % 8, entry i belongs to XCD i % 8
+  if (b < 0) return;
+  const int seq0 = cu[b], len = cu[b + 1] - seq0;
+  if (qt * TILE >= len) return;
+  const size_t ld = 3 * (size_t)D;
+  const bf16_t* qbase = qkv + (size_t)seq0 * ld + h * DH;
+  const float c = scale * LOG2E;
+  const int qrow0 = qt * TILE + wq * 32, qrow = qrow0 + li;
+  const bool idle = qrow0 >= len;   // (wave-uniform) none of this wave's query rows exists: it only feeds the DMA and the barriers
+
+  bf16x8 qfr[1][KS];
+  {
+    const int qr = min(qrow, len - 1);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qfr[0][ks] = *reinterpret_cast<const bf16x8*>(qbase + (size_t)qr * ld + ks * 16 + hi * 8);
+  }
+  // this wave's pieces: K records wq + 4 i (i < NKW), V records wq + 4 i (i < NVW); row inside the tile and element offset of the lane's 16 bytes
+  int krow[NKW], vrow_[NVW];
+  unsigned kcol[NKW], vcol[NVW];
+#pragma unroll
+  for (int i = 0; i < NKW; ++i) {
+    const int r = wq + 4 * i;
+    krow[i] = (r / KS) * 32 + li;
+    kcol[i] = D + (r % KS) * 16 + hi * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < NVW; ++i) {
+    const int r = wq + 4 * i;
+    vrow_[i] = (r / DB) * 16 + (l >> 2);
+    vcol[i] = 2 * D + (r % DB) * 32 + (l & 3) * 8;
+  }
+  const unsigned ldu = 3u * (unsigned)D;
+  const int nkt = (len + KVT - 1) / KVT;
+  const int valid_last = len - (nkt - 1) * KVT;                 // valid keys of the last tile (>= 1)
+  const int nkb_last = min(KB, (valid_last + 31) >> 5);         // its 32-key blocks that hold one
+  const BufRsrc qrs = make_rsrc(qbase);
+  int opq = 0;
+  asm volatile("" : "+s"(opq));   // (the LDS bases go through an opaque zero: see ffn_fused.hip)
+  bf16_t* const sKb = smem + h * HALF + opq;
+  bf16_t* const sVb = sKb + 2 * KSLOT;
+  auto fetch_k = [&](int kt, bf16_t* __restrict__ dst) {
+#pragma unroll
+    for (int i = 0; i < NKW; ++i) {
+      const unsigned off = (unsigned)min(kt * KVT + krow[i], len - 1) * ldu + kcol[i];
+      lds_dma16(qrs, dst + (wq + 4 * i) * 512, off * 2, 0);
+    }
+  };
+  auto fetch_v = [&](int kt, bf16_t* __restrict__ dst) {
+#pragma unroll
+    for (int i = 0; i < NVW; ++i) {
+      const unsigned off = (unsigned)min(kt * KVT + vrow_[i], len - 1) * ldu + vcol[i];
+      lds_dma16(qrs, dst + (wq + 4 * i) * 512, off * 2, 0);
+    }
+  };
+
+  f32x16 o[1][DB], s[KB];
+  bf16x8 pf[KP];
+  float m[1], ls[1];
+
+  int lx = l, vlast = valid_last;   // laundered at the top of every pass (run): what is derived from them must not be hoisted out of the pass loop
+  // ---- X: the matrix segment.  NB_PV / NB_S = the 32-key blocks of the P V tile / the S tile that are multiplied (KB except for the last tile)
+  auto seg_x = [&](const bf16_t* __restrict__ sV, const bf16_t* __restrict__ sK, auto pv_tag, auto s_tag) {
+    constexpr int NB_PV = decltype(pv_tag)::value, NB_S = decltype(s_tag)::value;
+    if (idle) return;
+    constexpr int NPV = 2 * NB_PV * DB, NS = NB_S * KS, N = NPV + NS, NBS = NB_S > 0 ? NB_S : 1;
+    // step order.  Two key blocks (dh 96): the P V steps (DB independent accumulators), then the S steps alternating between the two blocks' chains.
+    // One key block (dh 192): S is ONE dependent chain of KS MFMAs -- its steps alternate with the P V steps while both last.
+    constexpr bool MIX = (KB == 1) && NPV > 0 && NS > 0;
+    auto kind = [](int st, int& idx) {   // true = P V step idx, false = S step idx
+      if (MIX) {
+        constexpr int NM = (NPV < NS ? NPV : NS);
+        if (st < 2 * NM) { idx = st >> 1; return (st & 1) != 0; }
+        idx = st - NM;
+        return NPV > NS;
+      }
+      if (st < NPV) { idx = st; return true; }
+      idx = st - NPV;
+      return false;
+    };
+    const int g = lx >> 4, ii = lx & 15;
+    const bf16_t* vlane = sV + (4 * (g >> 1) + (ii >> 2)) * 32 + (g & 1) * 16 + (ii & 3) * 4;
+    auto rd = [&](int st) {
+      int idx = 0;
+      const bool is_pv = kind(st, idx);
+      if constexpr ((CHADA_P32_ABL & 2) != 0) return qfr[0][idx % KS];
+      if (is_pv) {   // idx = kp * DB + db
+        const bf16x4 lo = lds_read_tr4(vlane + idx * 512);
+        const bf16x4 hi4 = lds_read_tr4(vlane + idx * 512 + 8 * 32);
+        return (bf16x8)__builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+      const int kb = idx % NBS, ks = idx / NBS;
+      return lds_read8(sK + (kb * KS + ks) * 512 + lx * 8);
+    };
+    constexpr int PD = CHADA_P32_PD, NF = PD + 1;
+    bf16x8 fr[NF];
+#pragma unroll
+    for (int i = 0; i < PD; ++i)
+      if (i < N) fr[i % NF] = rd(i);
+#pragma unroll
+    for (int st = 0; st < N; ++st) {
+      if (st + PD < N) fr[(st + PD) % NF] = rd(st + PD);
+      __builtin_amdgcn_sched_barrier(0);
+      int idx = 0;
+      const bool is_pv = kind(st, idx);
+      if constexpr ((CHADA_P32_ABL & 4) != 0) {
+        if (is_pv) o[0][idx % DB][0] += (float)fr[st % NF][0]; else s[idx % NBS][0] += (float)fr[st % NF][1];
+      } else if (is_pv) {
+        o[0][idx % DB] = mfma32(fr[st % NF], pf[idx / DB], o[0][idx % DB]);
+      } else {
+        const int kb = idx % NBS, ks = idx / NBS;
+        s[kb] = mfma32(fr[st % NF], qfr[0][ks], ks == 0 ? splat16(0.f) : s[kb]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // ---- Y: softmax of tile kt (fwd_tile's arithmetic: MODE 1 = the first tile, takes the row maximum as the fixed reference; MODE 4 = the rest;
+  // REDO pass, half flagged `textbook`: fwd_tile's MODE 0 on every tile -- running maximum, O rescaled)
+  bool textbook = false;
+  auto seg_y = [&](int kt, auto mode_tag, auto masked_tag) {
+    constexpr int MODE = decltype(mode_tag)::value;
+    constexpr bool MASKED = decltype(masked_tag)::value;
+    if (idle) return;
+    const int valid = MASKED ? vlast : KVT;
+    const int nkb = MASKED ? nkb_last : KB;
+    if (MASKED) {
+      const int hx = lx >> 5;
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        if (kb >= nkb) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kb * 32 + 8 * (r >> 2) + 4 * hx + (r & 3) >= valid) s[kb][r] = -INFINITY;
+      }
+    }
+    float ps = 0.f;
+    if (MODE == 4 && !textbook) {
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        if (MASKED && kb >= nkb) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][r], c, -m[0]));
+          s[kb][r] = p;
+          ps += p;
+        }
+      }
+      ls[0] += ps;
+    } else {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        if (MASKED && kb >= nkb) continue;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, s[kb][r]), s[kb][r + 1]);
+      }
+      mx = half_max(mx);
+      const float mn = fmaxf(m[0], mx * c);
+      const float alpha = __builtin_amdgcn_exp2f(m[0] - mn);
+      m[0] = mn;
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        if (MASKED && kb >= nkb) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][r], c, -mn));
+          s[kb][r] = p;
+          ps += p;
+        }
+      }
+      ls[0] = ls[0] * alpha + ps;
+      if (textbook) {
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+#pragma unroll
+          for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[0][db][r] *= alpha;
+        }
+      }
+    }
+#pragma unroll
+    for (int kp = 0; kp < KP; ++kp) {
+      if (MASKED && (kp >> 1) >= nkb) continue;   // (never multiplied)
+      const f32x16& sv = s[kp >> 1];
+      const int b0 = 8 * (kp & 1);
+      pf[kp] = pack8f(sv[b0], sv[b0 + 1], sv[b0 + 2], sv[b0 + 3], sv[b0 + 4], sv[b0 + 5], sv[b0 + 6], sv[b0 + 7]);
+    }
+  };
+  using One = std::integral_constant<int, 1>;
+  using Full = std::integral_constant<int, KB>;
+  using None = std::integral_constant<int, 0>;
+  using M1 = std::integral_constant<int, 1>;
+  using M4 = std::integral_constant<int, 4>;
+
+  // ---- all key tiles of the item, both halves
+  auto run = [&]() {
+    asm volatile("" : "+v"(lx), "+s"(vlast));
+    m[0] = -INFINITY;
+    ls[0] = 0.f;
+#pragma unroll
+    for (int db = 0; db < DB; ++db) o[0][db] = splat16(0.f);
+    // prologue: K(0), K(1), V(0); the first barrier publishes them
+    fetch_k(0, sKb);
+    if (nkt > 1) fetch_k(1, sKb + KSLOT);
+    fetch_v(0, sVb);
+    // (the builtin, not asm: hipcc's wait insertion must KNOW that the Q fragment loads have landed -- attn_fwd_pair_kernel in attention.hip)
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    asm volatile("s_barrier" ::: "memory");
+    if (h == 1) asm volatile("s_barrier" ::: "memory");   // half B runs one segment behind
+    // X_0: S(0) only
+    if (nkt > 1 || KB == 1 || nkb_last == KB) seg_x(sVb, sKb, None{}, Full{}); else seg_x(sVb, sKb, None{}, One{});
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int kt = 0; kt < nkt - 1; ++kt) {
+      // Y_kt: the refills first (they go out while the exponentials run): K(kt + 2) over K(kt), V(kt + 1) over V(kt - 1)
+      if constexpr ((CHADA_P32_ABL & 1) == 0) {
+        if (kt + 2 < nkt) fetch_k(kt + 2, sKb + (kt & 1) * KSLOT);
+        fetch_v(kt + 1, sVb + ((kt + 1) & 1) * VSLOT);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr ((CHADA_P32_ABL & 8) == 0) {
+        if (kt == 0) seg_y(kt, M1{}, std::false_type{}); else seg_y(kt, M4{}, std::false_type{});
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      // X_{kt+1}: O += P(kt) V(kt), then S(kt + 1)
+      const bf16_t* sVc = sVb + (kt & 1) * VSLOT;
+      const bf16_t* sKn = sKb + ((kt + 1) & 1) * KSLOT;
+      if (KB == 1 || kt + 1 < nkt - 1 || nkb_last == KB) seg_x(sVc, sKn, Full{}, Full{}); else seg_x(sVc, sKn, Full{}, One{});
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    // the last tile: Y (masked softmax), then O += P V alone
+    if constexpr ((CHADA_P32_ABL & 8) == 0) {
+      if (nkt == 1) seg_y(0, M1{}, std::true_type{}); else seg_y(nkt - 1, M4{}, std::true_type{});
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    {
+      const bf16_t* sVc = sVb + ((nkt - 1) & 1) * VSLOT;
+      if (KB == 1 || nkb_last == KB) seg_x(sVc, sKb, Full{}, None{}); else seg_x(sVc, sKb, One{}, None{});
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (h == 0) asm volatile("s_barrier" ::: "memory");   // half A's trailing segment
+  };
+  if (CHADA_P32_PRIO && h == 1) __builtin_amdgcn_s_setprio(1);
+  // ---- pass 0: the lean softmax.  Its range check (attn_fwd_m32_kernel's): a half with a bad row runs the item again with the running-max
+  // recurrence -- ONE instance of the loop, run a second time with `textbook` set for that half (the block repeats the loop: its barriers are
+  // the block's; the other half repeats its lean pass and gets what it had).  (A second inlined instance of the loop, or the unpaired kernel's
+  // fwd_item, costs dh 192 44-300 spilled registers.)
+  float lt;
+  for (int pass = 0;; ++pass) {
+    run();
+    lt = half_sum(ls[0]);
+    if (pass == 1 || CHADA_P32_RERUN == 0) break;
+    const bool bad = !idle && !(lt < OVERFLOW_GUARD);
+    const bool wbad = __builtin_amdgcn_ballot_w64(bad) != 0;
+    int* flags = reinterpret_cast<int*>(smem);   // (every DMA has landed and every fragment read is done: the barriers above)
+    if (l == 0) flags[w] = wbad ? 1 : 0;
+    __syncthreads();
+    int any[2] = {0, 0};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) any[i >> 2] |= flags[i];
+    if ((any[0] | any[1]) == 0) break;
+    __syncthreads();   // everybody has read the flags before the re-run's first DMA may land on them
+    textbook = any[h] != 0;
+  }
+  if (idle) return;
+  const float inv = 1.0f / lt;
+  bf16_t* orow = out + (size_t)(seq0 + min(qrow, len - 1)) * D + h * DH + 8 * hi;
+#pragma unroll
+  for (int db = 0; db < DB; ++db)
+#pragma unroll
+    for (int q4 = 0; q4 < 4; q4 += 2) {
+      const f32x16& ov = o[0][db];
+      const u32x2 pa = __builtin_bit_cast(u32x2, pack4(ov[4 * q4] * inv, ov[4 * q4 + 1] * inv, ov[4 * q4 + 2] * inv, ov[4 * q4 + 3] * inv));
+      const u32x2 pb = __builtin_bit_cast(u32x2, pack4(ov[4 * q4 + 4] * inv, ov[4 * q4 + 5] * inv, ov[4 * q4 + 6] * inv, ov[4 * q4 + 7] * inv));
+      unsigned a0 = pa[0], a1 = pa[1], b0 = pb[0], b1 = pb[1];
+      swap32x(a0, b0);
+      swap32x(a1, b1);
+      if (qrow < len) *reinterpret_cast<u32x4*>(orow + db * 32 + 8 * q4) = u32x4{a0, a1, b0, b1};
+    }
+  if (hi == 0 && qrow < len) lse[(size_t)h * T + seq0 + qrow] = (m[0] + log2f(lt)) * LN2;
+}
 
 }  // namespace
 
@@ -414,6 +737,14 @@ extern "C" int chadavit_attn_fwd_m32(const chada_bf16* qkv_, chada_bf16* out_, f
 #define M32_LAUNCH(DHV, CBV, NWV, LEANV)                                                                                              \
   hipLaunchKernelGGL((attn_fwd_m32_kernel<DHV, CBV, NWV, LEANV>), dim3(n_work * (TILE / (NWV * 32 * CBV)) * H), dim3(64 * NWV), 0, s, qkv, out, \
                      lse, cu_seqlens, work, T, D, H, scale)
+  // the paired schedule (two heads of one 128-row tile per 512-thread block): CHADAVIT_ATTN_FWD_PAIR32=1 or variant 6
+  static const int pair32 = getenv("CHADAVIT_ATTN_FWD_PAIR32") ? atoi(getenv("CHADAVIT_ATTN_FWD_PAIR32")) : 0;
+  if (H == 2 && (dh == 96 || dh == 192) && (variant == 6 || (variant == 0 && pair32 > 0))) {
+    if (dh == 96) hipLaunchKernelGGL((attn_fwd_pair32_kernel<96>), dim3(n_work), dim3(512), 0, s, qkv, out, lse, cu_seqlens, work, T, D, scale);
+    else hipLaunchKernelGGL((attn_fwd_pair32_kernel<192>), dim3(n_work), dim3(512), 0, s, qkv, out, lse, cu_seqlens, work, T, D, scale);
+    CHADA_CHECK_LAUNCH();
+    return 0;
+  }
   const int lean = variant == 1 ? 0 : (variant == 2 ? 1 : 2);
   if (dh == 96) {
     if (lean == 0) M32_LAUNCH(96, 1, 4, 0);

@@ -208,6 +208,76 @@ def golden_step(name, D, PR, nch, sizes, n_large, epoch, clip_grad=0.0, lr=5e-4,
 
 
 # --------------------------------------------------------------------------------------
+TRAJ_PARAMS = ["backbone.cls_token", "backbone.pos_embed", "backbone.token_learner.proj.weight", "backbone.blocks.0.self_attn.in_proj_weight",
+               "backbone.blocks.5.linear1.weight", "backbone.blocks.11.linear2.weight", "backbone.blocks.11.norm2.weight", "backbone.norm.weight",
+               "head.mlp.0.weight", "head.mlp.4.weight", "head.last_layer.weight_v"]
+
+
+def golden_traj(name, D, PR, nch, sizes, n_large, steps=5, lr=5e-4, wd=1e-4, base_tau=0.99, max_steps=20, steps_per_epoch=3):
+    """Round 6: the state a training run CARRIES from step to step (every other golden is one step): the centre of step k in the loss of
+    step k + 1 (losses/dino.py:103-118), the EMA teacher of step k in the teacher forward of k + 1 (momentum.py:63-87, base.py:1250-1276),
+    AdamW's moments from step 2 on, tau's cosine schedule, and the epoch boundary (teacher temperature schedule, last layer frozen during
+    epoch 0: dino.py:367-376).  BASELINE configs[0] shape by default: Tiny, one-channel images, two global crops.  `steps` consecutive steps
+    of the unmodified reference, a NEW procedural batch every step (seed 7 + k), epoch = k // steps_per_epoch, Lightning's hook order
+    (training_step, backward, on_after_backward, optimizer.step, optimizer_zero_grad, on_train_batch_end's two updates)."""
+    cfg = refshim.dino_cfg(embed_dim=D, num_prototypes=PR, num_large_crops=n_large, num_small_crops=len(sizes) - n_large, lr=lr,
+                           weight_decay=wd, base_tau=base_tau)
+    model = ref.DINO(cfg)
+    model.load_state_dict(build_sd(D, PR))
+    params = model.learnable_params
+    for g in params:
+        g["params"] = list(g["params"])
+    opt = torch.optim.AdamW(params, lr=lr, weight_decay=wd)
+    named = dict(model.named_parameters())
+    out = {"D": D, "P": PR, "nch": np.asarray(nch), "sizes": np.asarray(sizes), "n_large": n_large, "steps": steps, "lr": lr, "wd": wd,
+           "base_tau": base_tau, "max_steps": max_steps, "steps_per_epoch": steps_per_epoch, "param_names": np.asarray(TRAJ_PARAMS)}
+    rec = {k: [] for k in ("loss", "epoch", "teacher_temp", "center", "center_sum", "tau_used", "tau_next", "momentum_z_rowsum", "momentum_z_rowsq",
+                           "z_rowsum", "z_rowsq", "student_sums", "teacher_sums", "student_sq", "teacher_sq", "grad_norm_total")}
+    for k in range(steps):
+        epoch = k // steps_per_epoch
+        model.current_epoch = epoch
+        if k % steps_per_epoch == 0:
+            model.on_train_epoch_start()
+        imgs = P.make_images(nch, sizes, seed=7 + k)
+        batch = ref.one_channel_collate_fn([(i, c, l) for i, (c, l) in enumerate(imgs)])
+        seen = {"head": [], "momentum_head": []}
+        hooks = [getattr(model, m).register_forward_hook(lambda m_, i_, o_, m=m: seen[m].append(o_.detach().clone())) for m in seen]
+        loss = model.training_step(batch, k)
+        for h in hooks:
+            h.remove()
+        loss.backward()
+        model.on_after_backward()
+        tot = 0.0
+        for n, p in model.named_parameters():
+            if n.startswith(("backbone.", "head.")) and p.grad is not None:
+                tot += p.grad.double().norm().item() ** 2
+        opt.step()
+        model.optimizer_zero_grad(epoch, k, opt)
+        tau_used = model.momentum_updater.cur_tau
+        for mp in model.momentum_pairs:  # base.py:1263-1266
+            model.momentum_updater.update(*mp)
+        model.momentum_updater.update_tau(cur_step=k + 1, max_steps=max_steps)  # base.py:1270-1273 (global_step after the optimiser step)
+        z, tz = torch.cat(seen["head"]).double(), torch.cat(seen["momentum_head"]).double()
+        rec["loss"].append(loss.item()); rec["epoch"].append(epoch)
+        rec["teacher_temp"].append(float(model.dino_loss_func.teacher_temp_schedule[epoch]))
+        rec["center"].append(f32(model.dino_loss_func.center)[0, :256]); rec["center_sum"].append(model.dino_loss_func.center.double().sum().item())
+        rec["tau_used"].append(tau_used); rec["tau_next"].append(model.momentum_updater.cur_tau)
+        rec["momentum_z_rowsum"].append(tz.sum(1).numpy()); rec["momentum_z_rowsq"].append((tz ** 2).sum(1).numpy())
+        rec["z_rowsum"].append(z.sum(1).numpy()); rec["z_rowsq"].append((z ** 2).sum(1).numpy())
+        rec["student_sums"].append([named[n].double().sum().item() for n in TRAJ_PARAMS])
+        rec["teacher_sums"].append([named["momentum_" + n].double().sum().item() for n in TRAJ_PARAMS])
+        rec["student_sq"].append([(named[n].double() ** 2).sum().item() for n in TRAJ_PARAMS])
+        rec["teacher_sq"].append([(named["momentum_" + n].double() ** 2).sum().item() for n in TRAJ_PARAMS])
+        rec["grad_norm_total"].append(tot ** 0.5)
+        print("traj step", k, "epoch", epoch, "loss", loss.item(), "tau", tau_used, flush=True)
+    out.update({k: np.asarray(v) for k, v in rec.items()})
+    out["post::backbone.norm.weight"] = f32(named["backbone.norm.weight"])
+    out["post::momentum_backbone.norm.weight"] = f32(named["momentum_backbone.norm.weight"])
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, rec["loss"])
+
+
+# --------------------------------------------------------------------------------------
 def golden_loss(name, B, PR, epoch):
     lf = ref.DINOLoss(num_prototypes=PR, warmup_teacher_temp=0.04, teacher_temp=0.07, warmup_teacher_temp_epochs=3,
                       num_epochs=10)
@@ -584,6 +654,11 @@ if __name__ == "__main__":
         # round 3: image sizes other than 224 / 96 -- 112 (7 x 7 patches), 100 (6 x 6, four pixels dropped by the stride-16 conv),
         # 32 (2 x 2), 16 (ONE patch per channel) and 448 (28 x 28: 2 353 tokens for three channels); bicubic position embedding each
         golden_backbone("backbone_tiny_sizes", 192, [2, 1, 3], [112, 100, 32, 16, 448], 61, 62)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "traj":
+        # round 6: five consecutive steps on BASELINE configs[0]'s shape (Tiny, four one-channel images, two global crops), the epoch
+        # boundary after step 3 (teacher temperature 0.04 -> 0.055, the last layer thawed)
+        golden_traj("traj_tiny_c1", 192, 4096, [1, 1, 1, 1], [224, 224], 2)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "attnmap":
         golden_attnmap("attnmap_tiny", 192, 2, 224, 51, 52)

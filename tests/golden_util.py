@@ -150,3 +150,49 @@ def grad_subsets_vs_golden(named, g, cos_min=0.99, norm_rel=6e-2):
             worst = (c, n)
     assert worst[0] >= cos_min, ("gradient spread vs the reference", worst)
     return worst
+
+
+def oracle_trajectory(g):
+    """Consecutive training steps of the CPU oracle on a trajectory golden's schedule (tests/golden/make_golden.py::golden_traj): a new
+    procedural batch every step (seed 7 + k), epoch = k // steps_per_epoch (teacher temperature, last layer frozen during epoch 0), AdamW as
+    torch runs it (the step count is PER PARAMETER: a tensor whose gradient was None during epoch 0 starts at 1 when it thaws), EMA with the
+    current tau, then the cosine tau update (base.py:1250-1276).  Returns one record per step with the golden's keys."""
+    import numpy as np
+    import torch
+    from oracle import chada_ref as R
+    D, PR = int(g["D"]), int(g["P"])
+    nch, sizes = [int(c) for c in g["nch"]], [int(s) for s in g["sizes"]]
+    lr, wd, tau, max_steps, spe = float(g["lr"]), float(g["wd"]), float(g["base_tau"]), int(g["max_steps"]), int(g["steps_per_epoch"])
+    names = [str(n) for n in g["param_names"]]
+    sd = build_sd(D, PR)
+    temps = R.teacher_temp_schedule(0.04, 0.07, 3, 10)
+    state = {}   # name -> (m, v, step)
+    recs = []
+    for k in range(int(g["steps"])):
+        epoch = k // spe
+        crops, _, ncl = R.collate(P.make_images(nch, sizes, seed=7 + k))
+        loss, grads, newc, aux = R.training_step(sd, crops, ncl, int(g["n_large"]), float(temps[epoch]), freeze_last_layer=epoch < 1)
+        tot = sum(float(v.double().norm()) ** 2 for v in grads.values() if v is not None) ** 0.5
+        for n, gr in grads.items():
+            if gr is None:
+                continue
+            m, v, st = state.get(n, (torch.zeros_like(sd[n]), torch.zeros_like(sd[n]), 0))
+            sd[n], m, v = R.adamw_step(sd[n], gr, m, v, st + 1, lr, wd)
+            state[n] = (m, v, st + 1)
+        sd["dino_loss_func.center"] = newc
+        tau_used = tau
+        for n in list(sd):
+            if n.startswith(("backbone.", "head.")) and not n.endswith(("running_mean", "running_var", "num_batches_tracked")):
+                tn = "momentum_" + n
+                sd[tn] = tau * sd[tn] + (1 - tau) * sd[n]
+        tau = R.tau_schedule(k + 1, max_steps, float(g["base_tau"]), 1.0)
+        z, tz = aux["student_logits"].double(), aux["teacher_logits"].double()
+        recs.append({"loss": float(loss), "center": newc[0, :256].numpy().copy(), "center_sum": float(newc.double().sum()), "tau_used": tau_used,
+                     "tau_next": tau, "teacher_temp": float(temps[epoch]), "grad_norm_total": tot,
+                     "z_rowsum": z.sum(1).numpy(), "z_rowsq": (z ** 2).sum(1).numpy(),
+                     "momentum_z_rowsum": tz.sum(1).numpy(), "momentum_z_rowsq": (tz ** 2).sum(1).numpy(),
+                     "student_sums": np.asarray([float(sd[n].double().sum()) for n in names]),
+                     "teacher_sums": np.asarray([float(sd["momentum_" + n].double().sum()) for n in names]),
+                     "student_sq": np.asarray([float((sd[n].double() ** 2).sum()) for n in names]),
+                     "teacher_sq": np.asarray([float((sd["momentum_" + n].double() ** 2).sum()) for n in names])})
+    return recs, sd

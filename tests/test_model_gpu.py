@@ -1229,6 +1229,77 @@ def test_two_steps_run_and_loss_moves():
     assert "dino_loss_func.center" in sd and "momentum_head.last_layer.weight_v" in sd and "backbone.blocks.11.norm2.bias" in sd
 
 
+@pytest.mark.parametrize("mode", ["eager", "graph"])
+def test_five_step_trajectory_vs_golden(mode):
+    """Round 6: state carried between steps.  Golden traj_tiny_c1 = five consecutive steps of the unmodified reference (BASELINE configs[0]'s
+    shape: Tiny, four one-channel images, two global crops; a new batch every step; the epoch boundary after step 3 moves the teacher
+    temperature and thaws the last layer).  The HIP path through the hook loop (Trainer.train_step) and through the whole-step hipGraph
+    (GraphedTrainStep): per step the loss (abs <= 2e-2), the centre that the next step's loss reads (abs <= 2e-3; losses/dino.py:103-118), tau
+    to 1e-12 (base.py:1270-1273), the teacher's logits (row sums of squares) and the EMA teacher's parameter sums (rel <= 1e-4;
+    momentum.py:63-87), the student's parameters after AdamW's moments have run on for five steps."""
+    from chadavit_amd.data.channels_strategies import one_channel_collate_fn
+    from chadavit_amd.graphed import GraphedTrainStep
+    from chadavit_amd.methods.dino import DINO
+    from chadavit_amd.trainer import Trainer
+    dev = _dev()
+    g = np.load(os.path.join(GOLDEN, "traj_tiny_c1.npz"))
+    D, PR, n_large = int(g["D"]), int(g["P"]), int(g["n_large"])
+    nch, sizes = [int(c) for c in g["nch"]], [int(s) for s in g["sizes"]]
+    spe = int(g["steps_per_epoch"])
+    model = DINO(_cfg(D, PR, n_large, len(sizes) - n_large, lr=float(g["lr"]), wd=float(g["wd"]), base_tau=float(g["base_tau"])))
+    model.load_state_dict(build_sd(D, PR))
+    model = model.to(dev)
+    tr = Trainer(max_epochs=10, steps_per_epoch=spe).attach(model)
+    tr.estimated_stepping_batches = int(g["max_steps"])
+    step = GraphedTrainStep(tr) if mode == "graph" else tr.train_step
+    names = [str(n) for n in g["param_names"]]
+    worst = {"loss": 0.0, "center": 0.0, "teacher_sum_rel": 0.0, "student_sq_rel": 0.0, "tz_sq_rel": 0.0}
+    for k in range(int(g["steps"])):
+        crops, labels, ncl = one_channel_collate_fn(P.make_images(nch, sizes, seed=7 + k))
+        batch = ([c.to(dev) for c in crops], labels.to(dev), ncl)
+        tr.current_epoch = k // spe
+        tau_used = model.momentum_updater.cur_tau
+        loss = float(step(batch, k % spe).item())
+        torch.cuda.synchronize()
+        assert abs(tau_used - float(g["tau_used"][k])) < 1e-12 and abs(model.momentum_updater.cur_tau - float(g["tau_next"][k])) < 1e-12, k
+        assert abs(model.dino_loss_func.teacher_temp_schedule[k // spe] - float(g["teacher_temp"][k])) < 1e-12
+        worst["loss"] = max(worst["loss"], abs(loss - float(g["loss"][k])))
+        assert abs(loss - float(g["loss"][k])) <= 2e-2, (mode, k, loss, float(g["loss"][k]))
+        c = model.dino_loss_func.center.float().cpu()
+        worst["center"] = max(worst["center"], float(np.abs(c[0, :256].numpy() - g["center"][k]).max()))
+        np.testing.assert_allclose(c[0, :256].numpy(), g["center"][k], atol=2e-3, rtol=0)
+        assert abs(float(c.double().sum()) - float(g["center_sum"][k])) <= 2e-3 * PR ** 0.5, k
+        named = dict(model.named_parameters())
+        for i, n in enumerate(names):
+            t, st = named["momentum_" + n].detach().double(), named[n].detach().double()
+            ref_t, ref_tq, ref_sq = float(g["teacher_sums"][k][i]), float(g["teacher_sq"][k][i]), float(g["student_sq"][k][i])
+            # the EMA teacher: a sum of N entries each within 1e-4 relative of the reference's
+            rel = abs(float(t.sum()) - ref_t) / (abs(ref_t) + ref_tq ** 0.5)
+            worst["teacher_sum_rel"] = max(worst["teacher_sum_rel"], rel)
+            assert rel <= 1e-4, (mode, k, n, float(t.sum()), ref_t)
+            assert abs(float((t ** 2).sum()) - ref_tq) <= 1e-4 * ref_tq, (mode, k, n)
+            # the student after k + 1 AdamW steps (every entry moves by ~lr per step whatever its gradient's size; bf16 gradients whose sign
+            # is noise move some entries the other way: the sums of squares stay within lr * steps * |w|_1-scale)
+            relq = abs(float((st ** 2).sum()) - ref_sq) / ref_sq
+            worst["student_sq_rel"] = max(worst["student_sq_rel"], relq)
+            assert relq <= 2e-3, (mode, k, n, relq)
+        if mode == "eager":   # what the teacher pass produced THIS step with the EMA weights of the step before
+            tz = model._last_outs["momentum_z"].detach().double().cpu()
+            rq = torch.from_numpy(g["momentum_z_rowsq"][k])
+            relz = float((((tz ** 2).sum(1) - rq).abs() / rq).max())
+            worst["tz_sq_rel"] = max(worst["tz_sq_rel"], relz)
+            assert relz <= 8e-2, (k, relz)
+            assert bool(((tz.sum(1) - torch.from_numpy(g["momentum_z_rowsum"][k])).abs() <= 0.16 * rq.sqrt()).all()), k
+    print("trajectory", mode, worst)
+    if mode == "graph":
+        assert len(step.graphs) == 2   # frozen / thawed last layer
+        step.close()
+    named = dict(model.named_parameters())
+    np.testing.assert_allclose(named["momentum_backbone.norm.weight"].detach().float().cpu().numpy(), g["post::momentum_backbone.norm.weight"], atol=2e-5, rtol=0)
+    d = np.abs(named["backbone.norm.weight"].detach().float().cpu().numpy() - g["post::backbone.norm.weight"])
+    assert d.max() <= 2.1 * int(g["steps"]) * float(g["lr"]) and (d > 5e-4).mean() <= 0.10, (d.max(), (d > 5e-4).mean())
+
+
 def test_training_memory_is_stable_across_steps():
     """Side-stream overlap must not make the caching allocator grow: after warm-up no new device segments appear
     (guards against record_stream-style deferred frees that made the reserved pool grow every step)."""

@@ -193,6 +193,38 @@ def test_training_step_matches_reference(name):
     assert abs(R.tau_schedule(1, int(g["max_steps"]), float(g["base_tau"]), 1.0) - float(g["tau_next"])) < 1e-12
 
 
+def test_five_step_trajectory_matches_reference():
+    """Round 6: the state CARRIED between steps (golden traj_tiny_c1: five consecutive steps of the unmodified reference on BASELINE
+    configs[0]'s shape -- Tiny, four one-channel images, two global crops -- a new batch every step, the epoch boundary after step 3).  The
+    oracle must reproduce every step to fp32 round-off: the centre of step k enters the loss of k + 1 (losses/dino.py:103-118), the EMA
+    teacher of step k the teacher pass of k + 1 (momentum.py:63-87), AdamW's moments and per-parameter step counts run on (the last layer
+    thaws at epoch 1: dino.py:374-376), tau follows its cosine (base.py:1270-1273)."""
+    from tests.golden_util import oracle_trajectory
+    g = _load("traj_tiny_c1")
+    recs, sd = oracle_trajectory(g)
+    assert len(recs) == int(g["steps"]) == 5
+    for k, r in enumerate(recs):
+        assert abs(r["loss"] - float(g["loss"][k])) <= 2e-6 * abs(float(g["loss"][k])), (k, r["loss"], float(g["loss"][k]))
+        assert r["teacher_temp"] == float(g["teacher_temp"][k])
+        np.testing.assert_allclose(r["center"], g["center"][k], atol=2e-6, rtol=0)
+        assert abs(r["center_sum"] - float(g["center_sum"][k])) <= 5e-5, k
+        assert abs(r["tau_used"] - float(g["tau_used"][k])) < 1e-12 and abs(r["tau_next"] - float(g["tau_next"][k])) < 1e-12, k
+        assert abs(r["grad_norm_total"] - float(g["grad_norm_total"][k])) <= 1e-4 * float(g["grad_norm_total"][k]), k
+        for key in ("z", "momentum_z"):   # both heads' logits, all 4096 columns: fp64 row sums and sums of squares
+            np.testing.assert_allclose(r[key + "_rowsum"], g[key + "_rowsum"][k], atol=1e-3, rtol=0)
+            np.testing.assert_allclose(r[key + "_rowsq"], g[key + "_rowsq"][k], rtol=1e-5)
+        # parameters: AdamW moves an entry whose gradient is rounding noise by lr in either direction -- sums of the student's tensors carry a
+        # few such flips (observed 4e-4), the EMA teacher 1 % of them
+        np.testing.assert_allclose(r["student_sums"], g["student_sums"][k], atol=4e-3, rtol=1e-6)
+        np.testing.assert_allclose(r["teacher_sums"], g["teacher_sums"][k], atol=2e-4, rtol=1e-6)
+        np.testing.assert_allclose(r["student_sq"], g["student_sq"][k], rtol=5e-6)
+        np.testing.assert_allclose(r["teacher_sq"], g["teacher_sq"][k], rtol=1e-6)
+    # the trajectory is not a fixed point: the loss moves by more than any tolerance above between every two steps
+    assert min(abs(float(a) - float(b)) for a, b in zip(g["loss"][:-1], g["loss"][1:])) > 0.03
+    np.testing.assert_allclose(sd["backbone.norm.weight"].numpy(), g["post::backbone.norm.weight"], atol=2e-6, rtol=0)
+    np.testing.assert_allclose(sd["momentum_backbone.norm.weight"].numpy(), g["post::momentum_backbone.norm.weight"], atol=1e-6, rtol=0)
+
+
 def test_lars_and_wd_split_match_reference():
     g = _load("lars")
     shapes = {"w0": (64, 48), "b0": (64,), "w1": (16, 64, 3), "g1": (16,), "z": (8, 8)}
