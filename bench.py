@@ -532,6 +532,19 @@ def replay_launches(counts, nch, wl, dev, reps=10):
     return out
 
 
+def rank_channels(wl, B, rank, world):
+    """(channel counts of this rank's B images, global-crop tokens of every rank or None) for a WORKLOADS entry.  Mixed-channel workloads:
+    ONE global batch of B * world images (same seed on every rank) split with data/sampler.py's token-balanced partition; fixed-channel
+    workloads: an independent draw per rank (all images cost the same).  (Its own function so that the first 8-GPU launch's partition --
+    cfg4: 8 x 128 -- is exercised by a gloo world-8 test on CPU: tests/test_parallel_cpu.py.)"""
+    if "-" in wl["channels"]:
+        from chadavit_amd.data.sampler import balanced_partition, image_cost
+        nch_global = channel_list(wl["channels"], B * world, seed=1000)
+        parts = balanced_partition([image_cost(c) for c in nch_global], world)
+        return [nch_global[i] for i in parts[rank]], [sum(1 + nch_global[i] * 196 for i in parts[r]) * wl["n_global"] for r in range(world)]
+    return channel_list(wl["channels"], B, seed=1000 + rank), None
+
+
 def build_workload(wl, args, rank, world, dev):
     """Model + Trainer (+ GradSync) + one synthetic batch resident in HBM for a WORKLOADS entry."""
     import torch
@@ -552,15 +565,7 @@ def build_workload(wl, args, rank, world, dev):
     # Mixed-channel workloads: ONE global batch of B * world images (same seed on every rank) is split with the token-balanced
     # partition of data/sampler.py -- equal image counts per rank, balanced N + N^2 cost -- instead of an independent draw per
     # rank, whose 17x per-image cost spread would make every step wait for the unluckiest rank.
-    tokens_per_rank = None
-    if "-" in wl["channels"]:
-        from chadavit_amd.data.sampler import balanced_partition, image_cost
-        nch_global = channel_list(wl["channels"], B * world, seed=1000)
-        parts = balanced_partition([image_cost(c) for c in nch_global], world)
-        nch = [nch_global[i] for i in parts[rank]]
-        tokens_per_rank = [sum(1 + nch_global[i] * 196 for i in parts[r]) * wl["n_global"] for r in range(world)]
-    else:
-        nch = channel_list(wl["channels"], B, seed=1000 + rank)
+    nch, tokens_per_rank = rank_channels(wl, B, rank, world)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     sizes = [224] * wl["n_global"] + [96] * wl["n_local"]
     # crops of one resolution lie back to back in one buffer, as the collate (data/channels_strategies.py) and the device

@@ -66,6 +66,83 @@ def test_span_allreduce_gloo_world2():
     assert all(b == (200 + 400 + 336) * 4 for _, _, b in res), res
 
 
+def _worker_cfg4(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    import bench
+    from chadavit_amd.parallel import SpanAllReduce, init_from_env
+    from chadavit_amd.ragged import RaggedBatch
+    r, w, _ = init_from_env("gloo")
+    wl = bench.WORKLOADS["cfg3"]            # cfg4 = cfg3's model and channel mix on 8 ranks x 128 images (BASELINE configs[3])
+    nch, tokens = bench.rank_channels(wl, wl["batch"], r, w)
+    mine = {"rank": r, "nch": nch, "tokens": tokens}
+    for p in (196, 36):                     # the 224-pixel and the 96-pixel crops' ragged descriptions, as the step builds them
+        rb = RaggedBatch(nch, p, "cpu")
+        work = rb.work.numpy()
+        items = work[work[:, 0] >= 0]
+        tile = 128
+        per_img = {}
+        for b, t in items.tolist():
+            per_img.setdefault(b, []).append(t)
+        ok = rb.n_work % 8 == 0 and len(per_img) == len(nch) and all(sorted(v) == list(range((1 + nch[b] * p + tile - 1) // tile)) for b, v in per_img.items())
+        # all tiles of an image sit in ONE residue class mod 8 (its XCD's sub-list)
+        pos = {}
+        for j, (b, t) in enumerate(work.tolist()):
+            if b >= 0:
+                pos.setdefault(b, set()).add(j % 8)
+        mine[f"work_ok_{p}"] = bool(ok and all(len(v) == 1 for v in pos.values()))
+        mine[f"n_work_{p}"] = int(rb.n_work)
+        mine[f"T_{p}"] = int(rb.T)
+    gathered = [None] * w
+    dist.all_gather_object(gathered, mine)
+    # the gradient spans' collective on eight ranks: mean over ranks, untouched gap
+    flat = torch.arange(512, dtype=torch.float32) * (r + 1)
+    red = SpanAllReduce()
+    for b, e in ((256, 512), (32, 256)):
+        red.submit(flat, b, e)
+    red.finish()
+    expect = torch.arange(512, dtype=torch.float32) * (sum(range(1, w + 1)) / w)
+    expect[:32] = torch.arange(32, dtype=torch.float32) * (r + 1)
+    q.put((r, gathered, bool(torch.allclose(flat, expect))))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_cfg4_batch_construction_gloo_world8():
+    """The first 8-GPU launch must not fail on partitioning (BASELINE configs[3]: Small, 1-10 channels, DDP 8 ranks, global batch 1024;
+    /root/reference/main_pretrain.py:301-306 shards with Lightning's DistributedSampler): eight gloo ranks build bench.py's batch for it --
+    every rank 128 images, together exactly the seeded global batch, global-crop tokens within 1 % across ranks, every rank's attention work
+    lists (224- and 96-pixel crops) a multiple of 8 with each image's tiles in one XCD class -- and run the span all-reduce on eight ranks."""
+    import bench
+    world = 8
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_cfg4, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=240) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    B = bench.WORKLOADS["cfg3"]["batch"]
+    assert B * world == 1024
+    glob = bench.channel_list("1-10", 1024, seed=1000)
+    for r, gathered, ok in res:
+        assert ok, r
+        assert [g["rank"] for g in gathered] == list(range(world))
+        assert gathered == res[0][1]                          # every rank saw the same eight descriptions
+    g = res[0][1]
+    assert all(len(x["nch"]) == B for x in g)
+    assert sorted(c for x in g for c in x["nch"]) == sorted(glob)
+    tokens = [sum(1 + c * 196 for c in x["nch"]) * 2 for x in g]
+    assert all(x["tokens"] == tokens for x in g)
+    assert max(tokens) / min(tokens) - 1.0 <= 0.01, tokens
+    for x in g:
+        assert x["work_ok_196"] and x["work_ok_36"] and x["n_work_196"] % 8 == 0 and x["n_work_36"] % 8 == 0
+        assert x["T_196"] * 2 == x["tokens"][x["rank"]]
+
+
 def test_library_exports_every_declared_symbol():
     """C-ABI contract: libchadavit_hip.so loads without a GPU and exports everything include/*.h declares."""
     from chadavit_amd import _lib
