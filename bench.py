@@ -82,7 +82,7 @@ class PowerSampler:
                 r = self._read()
                 if r is not None:
                     self.rows.append(r)
-                time.sleep(0.02)
+                time.sleep(0.2)   # 5 Hz: a read of power1_input queries the GPU's power controller -- not at 50 Hz inside the timed steps
         self._th = threading.Thread(target=loop, daemon=True)
         self._th.start()
 
@@ -103,7 +103,7 @@ class PowerSampler:
         return {"board_w": round(sum(r[0] for r in self.rows) / n, 1), "board_w_max": round(max(r[0] for r in self.rows), 1),
                 "cap_w": cap, "sclk_mhz": round(sum(r[1] for r in self.rows) / n, 1),
                 "before_first_launch": None if self.idle is None else {"board_w": round(self.idle[0], 1), "sclk_mhz": round(self.idle[1], 1)},
-                "samples": n, "source": "hwmon power1_input / freq1_input every 20 ms over the timed steps"}
+                "samples": n, "source": "hwmon power1_input / freq1_input every 200 ms over the timed steps"}
 
 
 WORKLOADS = {
@@ -926,6 +926,7 @@ def main():
     from chadavit_amd.parallel import GradSync, init_from_env
     from chadavit_amd.trainer import Trainer
 
+    os.environ.setdefault("CHADAVIT_DIST_TIMEOUT_S", "600")   # a dead rank takes the benchmark launch down instead of holding it for torch's half hour
     rank, world, local = init_from_env()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: chadavit_amd has no CPU path")

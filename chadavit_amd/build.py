@@ -79,5 +79,18 @@ def build(force: bool = False, verbose: bool = True, extra_flags=(), side: str |
     return lib_path
 
 
+AB_TAG, AB_FLAGS = "ab", ("-DCHADA_AB_SWITCHES=1",)
+
+
+def build_ab(verbose: bool = False) -> str:
+    """The A/B side build: the same sources with -DCHADA_AB_SWITCHES=1 -- the superseded kernels (16x16x32 LDS-DMA forward at dh 96 / 192 / 384, its
+    row-major-stage form, the fragment-major dQ kernel at dh 384) and the environment switches that select them or the weight-gradient GEMM's older
+    tilings.  Not part of the product: lives under scratch/sidebuild/ab/, loaded only with CHADAVIT_HIP_LIB=<path> CHADAVIT_ALLOW_FOREIGN_LIB=1 (the
+    bit-identity tests and same-box A/B runs do that in a child process)."""
+    return build(verbose=verbose, side=AB_TAG, extra_flags=AB_FLAGS)
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
+    if "--ab" in sys.argv:
+        print(build_ab(verbose=True))

@@ -22,6 +22,9 @@ using namespace chada;
 
 namespace {
 
+#ifndef CHADA_AB_SWITCHES
+#define CHADA_AB_SWITCHES 0   // 1 (side builds only): the superseded kernels and the environment switches that select them
+#endif
 constexpr int TILE = 128;  // rows per work item
 constexpr int KV = 64;     // rows staged per inner step
 constexpr float LOG2E = 1.4426950408889634f;
@@ -1826,20 +1829,25 @@ extern "C" int chadavit_attn_fwd(const chada_bf16* qkv_, chada_bf16* out_, float
   CHADA_ENTRY();
   if (!qkv_ || !out_ || !lse || !cu_seqlens || !work || n_work <= 0 || n_work % 8 != 0 || T <= 0 || H <= 0 || D % H != 0) return 1;
   const int dh = D / H;
-  // head widths 96 / 192: the 32x32x16-MFMA forward (attention_m32.hip).  CHADAVIT_ATTN_FWD_M32=-1 keeps the 16x16x32 kernels below
-  // (same-box A/B); 1 / 2 select its other softmax variants.
+  // head widths 96 / 192: the 32x32x16-MFMA forward (attention_m32.hip); dh 384: the paired schedule (attn_fwd_pair_kernel: bit-identical to
+  // attn_fwd_dma_kernel<384>, 908 -> 815-821 us on cfg5's global pass).  The kernels these replaced -- the 16x16x32 LDS-DMA forward at dh 96 / 192 /
+  // 384, its ROW-MAJOR-stage form -- and the environment switches that select them (CHADAVIT_ATTN_FWD_M32 = -1 / 1 / 2, CHADAVIT_ATTN_FWD_RM = 1,
+  // CHADAVIT_ATTN_FWD_PAIR = 0) exist only in side builds (-DCHADA_AB_SWITCHES=1: chadavit_amd.build.build(side="ab"), same-box A/B runs and the
+  // bit-identity tests); the product library has neither the switches nor those instances.
+#if CHADA_AB_SWITCHES
   static const int m32_variant = getenv("CHADAVIT_ATTN_FWD_M32") ? atoi(getenv("CHADAVIT_ATTN_FWD_M32")) : 0;
-  // CHADAVIT_ATTN_FWD_RM=1: the 16x16x32 forward on ROW-MAJOR stages (whole 128-byte lines per LDS-DMA instruction), dh 96 / 192 / 384
   static const int fwd_rm = getenv("CHADAVIT_ATTN_FWD_RM") ? atoi(getenv("CHADAVIT_ATTN_FWD_RM")) : 0;
-  // dh 384: the paired schedule (attn_fwd_pair_kernel: bit-identical to attn_fwd_dma_kernel<384>, 908 -> 815-821 us on cfg5's global pass);
-  // CHADAVIT_ATTN_FWD_PAIR=0 keeps the older kernel (same-box A/B, tests)
   static const int fwd_pair = getenv("CHADAVIT_ATTN_FWD_PAIR") ? atoi(getenv("CHADAVIT_ATTN_FWD_PAIR")) : 1;
+#else
+  constexpr int m32_variant = 0, fwd_rm = 0, fwd_pair = 1;
+#endif
   if (fwd_pair > 0 && fwd_rm <= 0 && dh == 384) {
     hipLaunchKernelGGL((attn_fwd_pair_kernel<384>), dim3(n_work * H), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const bf16_t*>(qkv_),
                        reinterpret_cast<bf16_t*>(out_), lse, cu_seqlens, work, T, D, H, 1.0f / sqrtf((float)dh));
     CHADA_CHECK_LAUNCH();
     return 0;
   }
+#if CHADA_AB_SWITCHES
   if (fwd_rm > 0 && (dh == 96 || dh == 192 || dh == 384)) {
     const bf16_t* qkv = reinterpret_cast<const bf16_t*>(qkv_);
     bf16_t* out = reinterpret_cast<bf16_t*>(out_);
@@ -1851,6 +1859,7 @@ extern "C" int chadavit_attn_fwd(const chada_bf16* qkv_, chada_bf16* out_, float
     CHADA_CHECK_LAUNCH();
     return 0;
   }
+#endif
   if (m32_variant >= 0 && (dh == 96 || dh == 192))
     return chadavit_attn_fwd_m32(qkv_, out_, lse, cu_seqlens, work, n_work, T, D, H, m32_variant, stream);
   const bf16_t* qkv = reinterpret_cast<const bf16_t*>(qkv_);
@@ -1872,11 +1881,14 @@ extern "C" int chadavit_attn_fwd(const chada_bf16* qkv_, chada_bf16* out_, float
     case 16:  // forward only (feature extraction with the 12-head default constructor); training uses the 2-head factory
       hipLaunchKernelGGL((attn_fwd_dma_kernel<16, 2>), dim3(n_work * H), blk, 0, s, qkv, out, lse, cu_seqlens, work, T, D, H, scale);
       break;
-    FWD_DMA_CASE(32, 2) FWD_DMA_CASE(64, 2) FWD_DMA_CASE(96, 2) FWD_DMA_CASE(192, 2)
+    FWD_DMA_CASE(32, 2) FWD_DMA_CASE(64, 2)
     FWD_CASE(128, 2) FWD_CASE(256, 1)   // embed_dim 256 / 512 with the factory's two heads: the register-staged kernels (cold path)
+#if CHADA_AB_SWITCHES   // (the product dispatches dh 96 / 192 / 384 above)
+    FWD_DMA_CASE(96, 2) FWD_DMA_CASE(192, 2)
     case 384:  // eight waves x 16 query rows per 128-row tile (FwdDmaCfg<384>::NW)
       hipLaunchKernelGGL((attn_fwd_dma_kernel<384, 1>), dim3(n_work * H), dim3(512), 0, s, qkv, out, lse, cu_seqlens, work, T, D, H, scale);
       break;
+#endif
     default: return 2;
   }
 #undef FWD_CASE
@@ -1946,12 +1958,14 @@ static int attn_bwd_launch(const chada_bf16* qkv_, const chada_bf16* out_, const
       if ((parts & 2) && fuse_delta) {
         // the row-major-stage kernel as eight waves x 16 rows (round 5: K fetched ONCE per tile and in whole 128-byte lines -- 48 KiB per tile instead of
         // the fragment-major kernel's 72, 96 KiB of LDS instead of 144; bit-identical; 1 261 -> 1 188 us on cfg5's global pass, ragged 939 -> 866).
-        // CHADAVIT_ATTN_DQ_RM=0 keeps attn_bwd_dq_fm_kernel (same-box A/B, tests)
+        // Side builds (-DCHADA_AB_SWITCHES=1) keep attn_bwd_dq_fm_kernel behind CHADAVIT_ATTN_DQ_RM=0 (same-box A/B, the bit-identity test)
+#if CHADA_AB_SWITCHES
         static const int dq_rm = getenv("CHADAVIT_ATTN_DQ_RM") ? atoi(getenv("CHADAVIT_ATTN_DQ_RM")) : 1;
-        if (dq_rm > 0)
-          hipLaunchKernelGGL((attn_bwd_dq_dma_kernel<384, 1, true, 8>), dim3(n_work * H), dim3(512), 0, s, qkv, dout, lse, delta, dqkv, cu_seqlens, work, T, D, H, scale, out);
+        if (dq_rm <= 0)
+          hipLaunchKernelGGL((attn_bwd_dq_fm_kernel<384, 1>), dim3(n_work * H), dim3(512), 0, s, qkv, dout, lse, delta, dqkv, cu_seqlens, work, T, D, H, scale, out);
         else
-        hipLaunchKernelGGL((attn_bwd_dq_fm_kernel<384, 1>), dim3(n_work * H), dim3(512), 0, s, qkv, dout, lse, delta, dqkv, cu_seqlens, work, T, D, H, scale, out);
+#endif
+        hipLaunchKernelGGL((attn_bwd_dq_dma_kernel<384, 1, true, 8>), dim3(n_work * H), dim3(512), 0, s, qkv, dout, lse, delta, dqkv, cu_seqlens, work, T, D, H, scale, out);
       }
       else if (parts & 2)   // (the fragment-major kernel always derives delta: the register-staged one serves the two-stream form)
         hipLaunchKernelGGL((attn_bwd_dq_kernel<384, 1, false>), dim3(n_work * 2 * H), blk, 0, s, qkv, dout, lse, delta, dqkv, cu_seqlens, work, T, D, H, scale, out);

@@ -9,6 +9,10 @@
 // the bias gradient colsum(A) rides along as one extra MFMA against an all-ones fragment.
 #include "common.h"
 
+#ifndef CHADA_AB_SWITCHES
+#define CHADA_AB_SWITCHES 0   // 1 (side builds only): environment switches for same-box A/B runs
+#endif
+
 using namespace chada;
 
 namespace {
@@ -293,11 +297,19 @@ extern "C" int chadavit_gemm_tn(const chada_bf16* A_, int lda, const chada_bf16*
     if (I % c[0] == 0 && J % c[1] == 0) { bi = c[0]; bj = c[1]; break; }
   // dW_qkv at D = 192 (576 x 192): three 192 x 192 tiles instead of nine 64 x 192 ones -- the shared operand h is pulled through LDS
   // three times instead of nine
+  // (A/B switches -- CHADA_TN_NO192, CHADA_TN_WIDE=0, CHADA_TN_OCC3=0, CHADA_TN_OLD_SPLITS -- exist in side builds only: -DCHADA_AB_SWITCHES=1)
+#if CHADA_AB_SWITCHES
   static const bool big = getenv("CHADA_TN_NO192") == nullptr;
+  static const int wide = getenv("CHADA_TN_WIDE") ? atoi(getenv("CHADA_TN_WIDE")) : 1;
+  static const bool occ3 = !(getenv("CHADA_TN_OCC3") && atoi(getenv("CHADA_TN_OCC3")) == 0);   // (0: the three-stage 128 x 192 kernel)
+  static const bool old_rule = getenv("CHADA_TN_OLD_SPLITS") != nullptr;   // (the round-2 split rule)
+#else
+  constexpr bool big = true, occ3 = true, old_rule = false;
+  constexpr int wide = 1;
+#endif
   if (big && bi == 64 && bj == 192 && I % 192 == 0 && I >= 384) bi = 192;
   // wide outputs (Base: 2304 x 768, 768 x 768): there the kernel is bound by the CU's vector-memory path (LDS-DMA, ~58 B/clk), not by
   // HBM, and a 192 x 192 tile stages 25 % fewer bytes per FLOP than 128 x 192
-  static const int wide = getenv("CHADA_TN_WIDE") ? atoi(getenv("CHADA_TN_WIDE")) : 1;
   if (wide && I % 192 == 0 && J % 192 == 0 && (long long)I * J >= 768ll * 768) { bi = 192; bj = 192; }
   const int tiles = (I / bi) * (J / bj);
   // T-splits.  tn_decode gives split s to XCD s % 8 (all tiles of a split share one L2), each XCD has 32 CUs x 2 resident blocks = 64
@@ -314,9 +326,7 @@ extern "C" int chadavit_gemm_tn(const chada_bf16* A_, int lda, const chada_bf16*
     const double t_full = fmax(2.0 * T * I * J / 0.95e15, 2.0 * T * (double)(I + J) / 4.6e12);   // seconds at full occupancy
     double best = 1e30;
     int best_n = 0;
-    const char* occ_env = getenv("CHADA_TN_OCC3");
-    const bool occ3_ = !(occ_env && atoi(occ_env) == 0) && bi == 128 && bj == 192;   // (CHADA_TN_OCC3=0: the three-stage kernel, A/B runs)
-    const int slots = occ3_ ? 96 : 64;
+    const int slots = (occ3 && bi == 128 && bj == 192) ? 96 : 64;   // (128 x 192 tiles: three blocks per CU)
     for (int n = 1; n <= 64; ++n) {
       if (8 * n > max_by_t || 8 * n > max_by_ws) break;
       const int rounds = (tiles * n + slots - 1) / slots;
@@ -325,7 +335,6 @@ extern "C" int chadavit_gemm_tn(const chada_bf16* A_, int lda, const chada_bf16*
     }
     splits = best_n ? 8 * best_n : (int)((max_by_ws < max_by_t ? max_by_ws : max_by_t) < 1 ? 1 : (max_by_ws < max_by_t ? max_by_ws : max_by_t));
   }
-  static const bool old_rule = getenv("CHADA_TN_OLD_SPLITS") != nullptr;   // (same-box A/B against the round-2 rule)
   if (old_rule) {
     splits = (512 + tiles - 1) / tiles;
     if (splits > max_by_t) splits = max_by_t;
@@ -336,8 +345,6 @@ extern "C" int chadavit_gemm_tn(const chada_bf16* A_, int lda, const chada_bf16*
   splits = (T + tchunk - 1) / tchunk;
   float* part = workspace;
   float* part_cs = colsumA ? workspace + (size_t)splits * I * J : nullptr;
-  const char* occ_env2 = getenv("CHADA_TN_OCC3");
-  const bool occ3 = !(occ_env2 && atoi(occ_env2) == 0);
 #define TN_CASE(a, b) \
   if (bi == a && bj == b) launch_tn<a, b>(A, lda, B, ldb, part, part_cs, T, I, J, tchunk, splits, s, occ3);
   TN_CASE(128, 192) TN_CASE(192, 128) TN_CASE(128, 128) TN_CASE(64, 192) TN_CASE(192, 64) TN_CASE(128, 64)

@@ -65,6 +65,9 @@ def tune_allocator_for_ragged_batches(divisions: int = 8) -> bool:
     return True
 
 
+_WARNED_ALLOCATOR: list = []   # (one warning per process)
+
+
 class DevicePrefetcher:
     def __init__(self, dataset, batch_sampler: Iterable[Sequence[int]], pipeline, depth: int = 2, workers: int = 8,
                  labels: Optional[Sequence[int]] = None, kernels_on: str = "producer", stream: Optional["torch.cuda.Stream"] = None,
@@ -83,6 +86,20 @@ class DevicePrefetcher:
         # tune_allocator: opt in to `tune_allocator_for_ragged_batches()` (process-wide; see there) -- worth it for variable-channel datasets
         if tune_allocator and self.device.type == "cuda":
             tune_allocator_for_ragged_batches()
+        elif self.device.type == "cuda" and callable(getattr(dataset, "num_channels", None)):
+            try:
+                mixed = len(set(dataset.num_channels())) > 1
+            except Exception:   # (a dataset whose channel counts are not known up front)
+                mixed = False
+            if mixed and not _WARNED_ALLOCATOR:
+                # variable-channel batches have a new set of buffer sizes every step: without the roundup option the caching allocator's reserved
+                # memory grew 147 -> 206 GiB in 150 steps and throughput fell ~10 % (profiles/r04t_*); the option is process-wide, hence opt-in
+                _WARNED_ALLOCATOR.append(True)
+                import logging
+                logging.getLogger("chadavit_amd").warning(
+                    "DevicePrefetcher: the dataset mixes channel counts and tune_allocator=False -- pass tune_allocator=True (or call "
+                    "chadavit_amd.data.loader.tune_allocator_for_ragged_batches() before the first GPU allocation) to keep the caching "
+                    "allocator's reserved memory flat with variable-size batches")
         self.read_s = 0.0      # host seconds spent decoding (sum over batches; the reader threads' wall time per batch)
         self.batches = 0
 

@@ -46,9 +46,13 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
         os.environ.setdefault("MASTER_PORT", "29533")
         # a finite rendezvous / collective timeout: a rank that died must not hold the others for torch's default half hour
         # (torchrun tears the group down on the first failed worker anyway; this covers launchers that do not)
-        from datetime import timedelta
-        dist.init_process_group(backend=backend, rank=rank, world_size=world,
-                                timeout=timedelta(seconds=int(os.environ.get("CHADAVIT_DIST_TIMEOUT_S", "600"))))
+        # (only when CHADAVIT_DIST_TIMEOUT_S is set -- bench.py sets 600 for its own launches; a training run keeps torch's default, so a
+        # rank doing long solo work -- checkpointing, k-NN evaluation -- while the others wait in a barrier is not cut off)
+        kw = {}
+        if os.environ.get("CHADAVIT_DIST_TIMEOUT_S"):
+            from datetime import timedelta
+            kw["timeout"] = timedelta(seconds=int(os.environ["CHADAVIT_DIST_TIMEOUT_S"]))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     elif torch.cuda.is_available():
         torch.cuda.set_device(local)
     return rank, world, local
@@ -180,6 +184,17 @@ class GradSync:
         self.reducer.reset_stats()
 
     def finish(self):
+        # A backbone pass parks the span that holds pos_embed while part of that gradient still travels through autograd
+        # (ChAdaViT._expect_pos_accumulation); pos_embed's post-accumulate hook releases it.  If that hook never fired in this backward
+        # (torch.autograd.grad / backward(inputs=...) without pos_embed, an exception on the way) the span would stay parked: its gradients
+        # would never be averaged this step and the stale hand-over would fire inside a LATER step, changing the collective order between
+        # ranks.  By now the backward has returned, so whatever autograd was going to add to pos_embed.grad has been added: hand it over here.
+        bb = getattr(self.model, "backbone", None)
+        if bb is not None and getattr(bb, "_pos_span_deferred", None) is not None:
+            deferred, bb._pos_span_deferred = bb._pos_span_deferred, None
+            bb._pos_autograd_pending = False
+            if self.reducer.active:
+                deferred()
         for p in self._plain:
             if p.grad is not None:
                 g = p.grad.view(-1)

@@ -8,7 +8,7 @@ pm() {  # tag op [env...]
   ( export "$@" GRAFT_DUMMY=1; ONE_OP_T=1206272 bash scratch/pmc.sh $op; python3 scratch/pmc_print.py gpurun_out/pmc_$op > $O/pmc_$tag.txt 2>&1; rm -rf gpurun_out/pmc_$op )
   echo "== $tag"; grep -A12 "attn_fwd" $O/pmc_$tag.txt | head -40
 }
-P=scratch/sidebuild/p32nr_prio/libchadavit_hip_p32nr_prio.so
+P=$GRAFT_REPO_ROOT/scratch/sidebuild/p32nr_prio/libchadavit_hip_p32nr_prio.so
 pm fwd96_unpaired_random attn_fwd
 pm fwd96_unpaired_zero attn_fwd ONE_OP_ZERO=1
 pm fwd96_paired_random attn_fwd CHADAVIT_ATTN_FWD_PAIR32=1 CHADAVIT_ALLOW_FOREIGN_LIB=1 CHADAVIT_HIP_LIB=$P

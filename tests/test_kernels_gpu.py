@@ -336,7 +336,7 @@ def test_attention_fwd_bwd(nch, p, D, H):
 def test_attention_dh384_round5_kernels_are_bit_identical_to_the_ones_they_replaced(tmp_path):
     """dh 384 dispatches attn_fwd_pair_kernel (the two waves of every SIMD in complementary phases, K ring of two / V ring of three, two barriers per key
     tile): same arithmetic in the same order as attn_fwd_dma_kernel<384> -- outputs and LSE must agree BIT FOR BIT with that kernel
-    (CHADAVIT_ATTN_FWD_PAIR=0, read once per process: child process) on ragged batches: 1961-token sequences, a last tile of one key (len 33 = 32 + 1),
+    (the A/B side build with CHADAVIT_ATTN_FWD_PAIR=0, read once per process: child process) on ragged batches: 1961-token sequences, a last tile of one key (len 33 = 32 + 1),
     a single tile, sequences shorter than a tile, waves without query rows."""
     import subprocess, sys, os
     from chadavit_amd import ops
@@ -360,8 +360,10 @@ for i, (nch, p) in enumerate(%r):
     outs.append((o.cpu(), l.cpu(), dqkv.cpu(), delta.cpu()))
 torch.save(outs, %r)
 """ % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), cases, str(tmp_path / "old.pt"))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CHADAVIT_ATTN_FWD_PAIR="0", CHADAVIT_ATTN_DQ_RM="0"), capture_output=True, text=True,
-                       timeout=600)
+    # (the replaced kernels and their switches live in the A/B side build only -- chadavit_amd.build.build_ab, -DCHADA_AB_SWITCHES=1 -- not in the product)
+    from chadavit_amd.build import build_ab
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CHADAVIT_ATTN_FWD_PAIR="0", CHADAVIT_ATTN_DQ_RM="0", CHADAVIT_HIP_LIB=build_ab(),
+                                                              CHADAVIT_ALLOW_FOREIGN_LIB="1"), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     old = torch.load(tmp_path / "old.pt")
     for i, (nch, p) in enumerate(cases):
@@ -378,7 +380,7 @@ torch.save(outs, %r)
 
 
 def test_attention_fwd_row_major_stages():
-    """A forward instance that the default dispatch does not use, kept for its measurement (profiles/r05o_*): the 16x16x32 forward on
+    """A forward instance of the A/B side build (not in the product library), kept for its measurement (profiles/r05o_*): the 16x16x32 forward on
     ROW-MAJOR LDS stages (CHADAVIT_ATTN_FWD_RM=1: whole 128-byte lines per LDS-DMA instruction, chunks swizzled on the source side; the switch is read
     once per process, hence the child process), dh 96 / 192 / 384, against fp32 torch on ragged batches incl. the 1961-token sequence and a last
     tile of 13 keys, LSE included."""
@@ -409,8 +411,9 @@ for D, nch, p in ((192, [3, 1, 10, 5], 196), (192, [1, 3, 2], 36), (384, [10, 2,
     assert float((o.float() - o_ref).abs().max()) < 2e-2 and float((l - l_ref).abs().max()) < 2e-3, ("row-major", D, nch)
 print("ok")
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, CHADAVIT_ATTN_FWD_RM="1")
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    from chadavit_amd.build import build_ab   # (a side-build instance: the product library has neither the kernel nor the switch)
+    env = dict(os.environ, CHADAVIT_ATTN_FWD_RM="1", CHADAVIT_HIP_LIB=build_ab(), CHADAVIT_ALLOW_FOREIGN_LIB="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-4000:]
 
 

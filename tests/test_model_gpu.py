@@ -933,7 +933,7 @@ def test_partially_frozen_backbone_and_head():
 
 @pytest.mark.parametrize("workload", ["cfg2", "cfg5"])
 def test_bench_scale_step_is_deterministic(workload):
-    """bench.py's own workload (cfg2: 512 images, 603 136 token rows per global pass; cfg5: Base, fp8 path, side streams on) built
+    """bench.py's own workload (cfg2: 1 024 images, 1 206 272 token rows per global pass; cfg5: Base, fp8 path, side streams on) built
     three times from the same seeds with the allocator's free blocks refilled in between: the loss and every gradient tensor of the
     first training step bit-identical -- every kernel of the step at the size the benchmark times it (scratch/r3/fuzz_bench_scale.py
     as a test; the teacher pass's QKV race of DESIGN section 0 made this differ in every run)."""
@@ -1068,7 +1068,7 @@ def test_training_step_with_batchnorm_in_the_head_vs_golden_and_oracle():
 
 
 @pytest.mark.parametrize("name,R_,rows,weight_dtype", [("step_tiny_multicrop", 170, 600780, "bf16"), ("step_small_mixed", 70, 274820, "bf16"),
-                                                       pytest.param("step_base_c10", 25, 127500, "bf16", marks=pytest.mark.slow),   # (23 s; the fp8 twin stays in the default run)
+                                                       ("step_base_c10", 25, 127500, "bf16"),   # (23 s; back in the default run since round 6)
                                                        ("step_base_c10", 25, 127500, "fp8"),
                                                        # 2.35 x the bench's rows: activations past 32-bit element and byte offsets
                                                        pytest.param("step_tiny_multicrop", 400, 1413600, "bf16", marks=pytest.mark.slow)])
@@ -1253,7 +1253,8 @@ def test_five_step_trajectory_vs_golden(mode):
     tr.estimated_stepping_batches = int(g["max_steps"])
     step = GraphedTrainStep(tr) if mode == "graph" else tr.train_step
     names = [str(n) for n in g["param_names"]]
-    worst = {"loss": 0.0, "center": 0.0, "teacher_sum_rel": 0.0, "student_sq_rel": 0.0, "tz_sq_rel": 0.0}
+    worst = {"loss": 0.0, "center": 0.0, "student_sq_rel": 0.0, "tz_sq_rel": 0.0}
+    bad = []
     for k in range(int(g["steps"])):
         crops, labels, ncl = one_channel_collate_fn(P.make_images(nch, sizes, seed=7 + k))
         batch = ([c.to(dev) for c in crops], labels.to(dev), ncl)
@@ -1270,19 +1271,30 @@ def test_five_step_trajectory_vs_golden(mode):
         np.testing.assert_allclose(c[0, :256].numpy(), g["center"][k], atol=2e-3, rtol=0)
         assert abs(float(c.double().sum()) - float(g["center_sum"][k])) <= 2e-3 * PR ** 0.5, k
         named = dict(model.named_parameters())
+        lr_, steps_done = float(g["lr"]), k + 1
         for i, n in enumerate(names):
             t, st = named["momentum_" + n].detach().double(), named[n].detach().double()
-            ref_t, ref_tq, ref_sq = float(g["teacher_sums"][k][i]), float(g["teacher_sq"][k][i]), float(g["student_sq"][k][i])
-            # the EMA teacher: a sum of N entries each within 1e-4 relative of the reference's
-            rel = abs(float(t.sum()) - ref_t) / (abs(ref_t) + ref_tq ** 0.5)
-            worst["teacher_sum_rel"] = max(worst["teacher_sum_rel"], rel)
-            assert rel <= 1e-4, (mode, k, n, float(t.sum()), ref_t)
-            assert abs(float((t ** 2).sum()) - ref_tq) <= 1e-4 * ref_tq, (mode, k, n)
-            # the student after k + 1 AdamW steps (every entry moves by ~lr per step whatever its gradient's size; bf16 gradients whose sign
-            # is noise move some entries the other way: the sums of squares stay within lr * steps * |w|_1-scale)
+            ref_t, ref_tq, ref_sq, ref_s = float(g["teacher_sums"][k][i]), float(g["teacher_sq"][k][i]), float(g["student_sq"][k][i]), float(g["student_sums"][k][i])
+            # AdamW moves EVERY entry by ~lr per step whatever its gradient's size, so an entry whose gradient is rounding noise under bf16 may go
+            # the other way: 2 lr per step and entry, signs independent -> a tensor's SUM differs by a random walk of sqrt(N) such steps (3 sigma);
+            # the EMA teacher inherits (1 - tau) of the student's deviation per step (tau >= 0.99 here).  A wrong tau (by 1e-4), a skipped update or
+            # a stale shadow moves these sums by far more: |teacher - student| ~ the weights themselves.
+            walk = 3.0 * t.numel() ** 0.5 * 2.0 * lr_ * steps_done
+            d_t, d_s = abs(float(t.sum()) - ref_t), abs(float(st.sum()) - ref_s)
+            worst["teacher_sum_over_bound"] = max(worst.get("teacher_sum_over_bound", 0.0), d_t / (0.01 * steps_done * walk + 1e-5 * abs(ref_t) + 1e-6))
+            worst["student_sum_over_bound"] = max(worst.get("student_sum_over_bound", 0.0), d_s / (walk + 1e-5 * abs(ref_s) + 1e-6))
+            if d_t > 0.01 * steps_done * walk + 1e-5 * abs(ref_t) + 1e-6:
+                bad.append((mode, k, n, "teacher sum", float(t.sum()), ref_t))
+            if d_s > walk + 1e-5 * abs(ref_s) + 1e-6:
+                bad.append((mode, k, n, "student sum", float(st.sum()), ref_s))
+            relt = abs(float((t ** 2).sum()) - ref_tq) / ref_tq
             relq = abs(float((st ** 2).sum()) - ref_sq) / ref_sq
+            worst["teacher_sq_rel"] = max(worst.get("teacher_sq_rel", 0.0), relt)
             worst["student_sq_rel"] = max(worst["student_sq_rel"], relq)
-            assert relq <= 2e-3, (mode, k, n, relq)
+            if relt > 1e-4:
+                bad.append((mode, k, n, "teacher sum of squares", relt))
+            if relq > 2e-3:
+                bad.append((mode, k, n, "student sum of squares", relq))
         if mode == "eager":   # what the teacher pass produced THIS step with the EMA weights of the step before
             tz = model._last_outs["momentum_z"].detach().double().cpu()
             rq = torch.from_numpy(g["momentum_z_rowsq"][k])
@@ -1291,6 +1303,7 @@ def test_five_step_trajectory_vs_golden(mode):
             assert relz <= 8e-2, (k, relz)
             assert bool(((tz.sum(1) - torch.from_numpy(g["momentum_z_rowsum"][k])).abs() <= 0.16 * rq.sqrt()).all()), k
     print("trajectory", mode, worst)
+    assert not bad, bad[:8]
     if mode == "graph":
         assert len(step.graphs) == 2   # frozen / thawed last layer
         step.close()

@@ -357,7 +357,7 @@ def test_bench_power_sampler_reads_the_gpus_own_hwmon_and_degrades_to_none(tmp_p
     ps = bench.PowerSampler(fake, 0)
     assert seen == ["/sys/bus/pci/devices/0000:75:00.0/hwmon/hwmon*"] and ps.idle == (1370.0, 1938.0)
     ps.start()
-    time.sleep(0.15)
+    time.sleep(0.5)   # (the sampler reads at 5 Hz)
     out = ps.stop()
     assert out["board_w"] == 1370.0 and out["sclk_mhz"] == 1938.0 and out["cap_w"] == 1400.0 and out["samples"] >= 2
     monkeypatch.setattr(_glob, "glob", lambda pat: [])
