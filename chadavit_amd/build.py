@@ -41,10 +41,11 @@ def side_lib(tag: str) -> str:
     return os.path.join(SIDE, tag, f"libchadavit_hip_{tag}.so")
 
 
-def build(force: bool = False, verbose: bool = True, extra_flags=(), side: str | None = None, csrc: str = CSRC) -> str:
+def build(force: bool = False, verbose: bool = True, extra_flags=(), side: str | None = None, csrc: str = CSRC, units=None) -> str:
     """side = a tag: a second build of the same ABI (same-box A/B of compiler options / kernel variants) under scratch/sidebuild/<tag>/,
     never inside the package; load it with CHADAVIT_HIP_LIB=<path> CHADAVIT_ALLOW_FOREIGN_LIB=1.  csrc: another source directory (a
-    checkout of an older commit) for such a build."""
+    checkout of an older commit) for such a build.  units: the sources `extra_flags` apply to (a side build of ONE kernel variant): the other
+    objects are the product build's own (built first if stale)."""
     hipcc = _hipcc()
     lib_path = LIB if side is None else side_lib(side)
     objdir = os.path.join(HERE, "build") if side is None else os.path.join(SIDE, side)
@@ -53,8 +54,13 @@ def build(force: bool = False, verbose: bool = True, extra_flags=(), side: str |
     headers = [os.path.join(CSRC_, "common.h"), os.path.join(ROOT, "include", "chadavit_hip.h")]
     jobs = []
     objs = []
+    if units is not None and side is not None:
+        build(verbose=False)   # the product objects the other units are taken from
     for src in SOURCES:
         sp = os.path.join(CSRC_, src)
+        if units is not None and side is not None and src not in units:
+            objs.append(os.path.join(HERE, "build", src.replace(".hip", ".o")))
+            continue
         op = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(op)
         deps = [sp] + headers + ([os.path.join(CSRC_, "ffn_fused.hip")] if src == "ffn_fused_d384.hip" else [])

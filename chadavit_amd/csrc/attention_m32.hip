@@ -107,6 +107,9 @@ __device__ __forceinline__ WorkItem decode_work(const int* __restrict__ work, in
 // One key tile.  MODE 0: textbook online softmax (running max m, rescale);  MODE 1: the first tile of the diet path (takes the
 // row maximum, which becomes the fixed reference held in `minit` = -m);  MODE 2: diet steady state (no max, no FMA, no rescale).
 // In MODE 1 / 2 the Q fragments carry the scale (c == 1 is passed).
+#ifndef CHADA_M32_ABL
+#define CHADA_M32_ABL 0   // timing-only ablations of the unpaired kernel (wrong results): 1 = no refills, 2 = no fragment reads, 8 = no softmax
+#endif
 template <int DH, int CB, int NW, int MODE, bool MASKED>
 __device__ __forceinline__ void fwd_tile(BufRsrc qb, bf16_t* __restrict__ dst, const bf16_t* __restrict__ sK, bool issue, int kt, int len,
                                          int qrow0, unsigned ldu, float c, int w, int l, const int (&rec_row)[Cfg<DH, CB, NW>::NRW],
@@ -115,7 +118,7 @@ __device__ __forceinline__ void fwd_tile(BufRsrc qb, bf16_t* __restrict__ dst, c
   using C = Cfg<DH, CB, NW>;
   constexpr int KS = C::KS, DB = C::DB, KB = C::KB, KP = C::KP, KVT = C::KVT, NKR = C::NKR, NRW = C::NRW;
   const int hi = l >> 5;
-  if (issue) {
+  if (issue && (CHADA_M32_ABL & 1) == 0) {
 #pragma unroll
     for (int i = 0; i < NRW; ++i) {
       const unsigned off = (unsigned)min((kt + 1) * KVT + rec_row[i], len - 1) * ldu + rec_col[i];
@@ -138,7 +141,7 @@ __device__ __forceinline__ void fwd_tile(BufRsrc qb, bf16_t* __restrict__ dst, c
     if (MASKED && kb >= nkb) continue;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const bf16x8 kf = lds_read8(sK + (kb * KS + ks) * 512 + l * 8);
+      const bf16x8 kf = (CHADA_M32_ABL & 2) ? qf[0][(ks + kb) % KS] : lds_read8(sK + (kb * KS + ks) * 512 + l * 8);
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb) {
         if (ks == 0)
@@ -161,7 +164,9 @@ __device__ __forceinline__ void fwd_tile(BufRsrc qb, bf16_t* __restrict__ dst, c
       }
     }
     float ps = 0.f;
-    if (MODE == 4) {  // fixed reference m (taken from the first tile), exact scores: one FMA + exp per score, no maximum
+    if (CHADA_M32_ABL & 8) {
+      ls[cb] += s[cb][0][0];
+    } else if (MODE == 4) {  // fixed reference m (taken from the first tile), exact scores: one FMA + exp per score, no maximum
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) {
         if (MASKED && kb >= nkb) continue;
@@ -235,9 +240,14 @@ __device__ __forceinline__ void fwd_tile(BufRsrc qb, bf16_t* __restrict__ dst, c
     const bf16_t* vrow = sV + kp * DB * 512 + (4 * (g >> 1) + (ii >> 2)) * 32 + (g & 1) * 16 + (ii & 3) * 4;
 #pragma unroll
     for (int db = 0; db < DB; ++db) {
-      const bf16x4 lo = lds_read_tr4(vrow + db * 512);
-      const bf16x4 hi4 = lds_read_tr4(vrow + db * 512 + 8 * 32);
-      const bf16x8 vf = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+      bf16x8 vf;
+      if (CHADA_M32_ABL & 2) {
+        vf = qf[0][(db + kp) % KS];
+      } else {
+        const bf16x4 lo = lds_read_tr4(vrow + db * 512);
+        const bf16x4 hi4 = lds_read_tr4(vrow + db * 512 + 8 * 32);
+        vf = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb) o[cb][db] = mfma32(vf, pf[cb], o[cb][db]);
     }

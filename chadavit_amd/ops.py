@@ -64,7 +64,8 @@ class LaunchProfiler:
 
     def __init__(self, only=None):
         self.records = []
-        self.only = only  # restrict the event pairs to one (entry point, shape) key: negligible perturbation of the step
+        # restrict the event pairs to one (entry point, shape) key or a set of them: negligible perturbation of the step
+        self.only = None if only is None else (set(only) if isinstance(only, (set, frozenset, list)) else {only})
 
     def __enter__(self):
         global _PROF
@@ -96,7 +97,7 @@ def _timed(keyfn):
             prof = _PROF
             if prof is None:
                 return fn(*a, **k)
-            if prof.only is not None and keyfn(*a, **k) != prof.only:
+            if prof.only is not None and keyfn(*a, **k) not in prof.only:
                 return fn(*a, **k)
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
