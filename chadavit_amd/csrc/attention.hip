@@ -1143,6 +1143,9 @@ __device__ __forceinline__ int dkv_swz(int row) {
   else return (4 - ((row >> 2) & 3)) & 3;
 }
 
+#ifndef CHADA_BWD_ABL
+#define CHADA_BWD_ABL 0   // timing-only ablations of the LDS-DMA backward kernels (wrong results): 1 = no refills, 2 = no fragment reads, 8 = no exp / dS arithmetic
+#endif
 template <int DH, int CBK, bool MASKED>
 __device__ __forceinline__ void attn_dkv_tile(BufRsrc qg, BufRsrc dog, BufRsrc lg, BufRsrc dg,
                                               bf16_t* __restrict__ dst, const bf16_t* __restrict__ rd, bool issue, bool idle, int q0, int len,
@@ -1172,7 +1175,7 @@ __device__ __forceinline__ void attn_dkv_tile(BufRsrc qg, BufRsrc dog, BufRsrc l
       lds_dma4(dg, dst + 2 * TILE_E + 2 * KVT, qr * 4, 0);
     }
   };
-  if (issue && (!SPREAD || idle)) {
+  if (issue && (!SPREAD || idle) && (CHADA_BWD_ABL & 1) == 0) {
 #pragma unroll
     for (int i = 0; i <= NRW; ++i) issue_piece(i);
   }
@@ -1190,6 +1193,7 @@ __device__ __forceinline__ void attn_dkv_tile(BufRsrc qg, BufRsrc dog, BufRsrc l
   auto row_read = [&](int step, bf16x8& qfr, bf16x8& dofr) {  // step = (k2 * 2 + q2) * KS + ks
     const int row = (step / KS) * 16 + li, ks = step % KS;
     const int ch = (ks * 4 + g) ^ dkv_swz<DH>(row);  // chunk ks*4 + g of the row, swizzled on its low two bits
+    if constexpr ((CHADA_BWD_ABL & 2) != 0) { qfr = kf[0][ks]; dofr = vf[0][ks]; return; }
     qfr = lds_read8(sQ + row * DH + ch * 8);
     dofr = lds_read8(sO + row * DH + ch * 8);
   };
@@ -1199,6 +1203,7 @@ __device__ __forceinline__ void attn_dkv_tile(BufRsrc qg, BufRsrc dog, BufRsrc l
     const int trow = k2 * 32 + 4 * g + (li >> 2);
     const int ch = (2 * db + ((li & 3) >> 1)) ^ dkv_swz<DH>(trow);  // the swizzle term is identical for trow + 16
     const int off = trow * DH + ch * 8 + (li & 1) * 4;
+    if constexpr ((CHADA_BWD_ABL & 2) != 0) { dot = kf[0][db % KS]; qtf = vf[0][db % KS]; return; }
     dot = __builtin_shufflevector(lds_read_tr4(sO + off), lds_read_tr4(sO + off + 16 * DH), 0, 1, 2, 3, 4, 5, 6, 7);
     qtf = __builtin_shufflevector(lds_read_tr4(sQ + off), lds_read_tr4(sQ + off + 16 * DH), 0, 1, 2, 3, 4, 5, 6, 7);
   };
@@ -1225,7 +1230,7 @@ __device__ __forceinline__ void attn_dkv_tile(BufRsrc qg, BufRsrc dog, BufRsrc l
 #pragma unroll
     for (int st = 0; st < 2 * KS; ++st) {
       const int q2 = st / KS, ks = st % KS, cur = st % R, nxt = st + RD;
-      if constexpr (SPREAD) {   // one piece per step of the first half instead of a burst behind the barrier
+      if constexpr (SPREAD && (CHADA_BWD_ABL & 1) == 0) {   // one piece per step of the first half instead of a burst behind the barrier
         if (issue && k2 == 0 && st <= NRW) issue_piece(st);
       }
       if (nxt < 2 * KS) row_read(k2 * 2 * KS + nxt, qfr[nxt % R], dofr[nxt % R]);
@@ -1251,6 +1256,7 @@ __device__ __forceinline__ void attn_dkv_tile(BufRsrc qg, BufRsrc dog, BufRsrc l
         }
         continue;
       }
+      if constexpr ((CHADA_BWD_ABL & 8) != 0) continue;
       const f32x4 l4 = *reinterpret_cast<const f32x4*>(sL + qb * 16 + 4 * g) * LOG2E;
       const f32x4 d4 = *reinterpret_cast<const f32x4*>(sD + qb * 16 + 4 * g);
 #pragma unroll
@@ -1399,7 +1405,7 @@ __device__ __forceinline__ void attn_dq_tile(BufRsrc kg, BufRsrc vg, bf16_t* __r
   const int g = l >> 4;
   int li = l & 15;
   if constexpr (NW == 8) asm volatile("" : "+v"(li));   // (dh 384, 192 registers of Q / dO / dQ state: keeps the tile's swizzled fragment addresses from being hoisted out of the tile loop)
-  if (issue) {
+  if (issue && (CHADA_BWD_ABL & 1) == 0) {
     const int r0 = (kt + 1) * KVT;
 #pragma unroll
     for (int i = 0; i < NRW; ++i) {
@@ -1415,6 +1421,7 @@ __device__ __forceinline__ void attn_dq_tile(BufRsrc kg, BufRsrc vg, bf16_t* __r
   auto row_read = [&](int step, bf16x8& kfr, bf16x8& vfr) {  // step = (k2 * 2 + k1) * KS + ks
     const int row = (step / KS) * 16 + li, ks = step % KS;
     const int ch = (ks * 4 + g) ^ dkv_swz<DH>(row);
+    if constexpr ((CHADA_BWD_ABL & 2) != 0) { kfr = qf[0][ks]; vfr = dof[0][ks]; return; }
     kfr = lds_read8(sK + row * DH + ch * 8);
     vfr = lds_read8(sV + row * DH + ch * 8);
   };
@@ -1422,7 +1429,8 @@ __device__ __forceinline__ void attn_dq_tile(BufRsrc kg, BufRsrc vg, bf16_t* __r
     const int trow = k2 * 32 + 4 * g + (li >> 2);
     const int ch = (2 * db + ((li & 3) >> 1)) ^ dkv_swz<DH>(trow);
     const int off = trow * DH + ch * 8 + (li & 1) * 4;
-    return __builtin_shufflevector(lds_read_tr4(sK + off), lds_read_tr4(sK + off + 16 * DH), 0, 1, 2, 3, 4, 5, 6, 7);
+    if constexpr ((CHADA_BWD_ABL & 2) != 0) return qf[0][db % KS];
+    return (bf16x8)__builtin_shufflevector(lds_read_tr4(sK + off), lds_read_tr4(sK + off + 16 * DH), 0, 1, 2, 3, 4, 5, 6, 7);
   };
   // (two / three groups of look-ahead instead of one / two measured the same: 739 vs 736 us for the whole backward)
   // last key tile of the sequence: only the 16-key blocks that hold a valid key are multiplied (len = 589: 13 keys = one
@@ -1461,6 +1469,7 @@ __device__ __forceinline__ void attn_dq_tile(BufRsrc kg, BufRsrc vg, bf16_t* __r
           s[cb][k1] = f32x4{0.f, 0.f, 0.f, 0.f};
           continue;
         }
+        if constexpr ((CHADA_BWD_ABL & 8) != 0) continue;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float p = __builtin_amdgcn_exp2f(fmaf(s[cb][k1][r], c, -L2[cb]));

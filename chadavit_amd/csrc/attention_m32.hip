@@ -74,6 +74,22 @@ __device__ __forceinline__ float half_sum(float v) {
   return a + b;
 }
 
+// Row-major stages (round 6).  CHADA_M32_RM = 1: a K / V tile is staged as its ROW-MAJOR image (rows of DH bf16, 64 consecutive 16-byte chunks per
+// LDS-DMA instruction: 11-12 lines of 128 bytes touched instead of the fragment records' 32 -- 24-27 cycles of the CU's address path instead of a
+// flat 64, profiles/r05o_*), the 16-byte chunks of a row XOR-swizzled on the SOURCE side (the DMA writes lane-linear) so that the 32x32x16
+// fragment reads stay conflict-free: K fragments by ds_read_b128 of row (l & 31), chunk 2 ks + (l >> 5); V^T fragments by the transpose read of
+// the row-major tile.  The swizzles (brute force over the measured ds_read_b128 lane groups {0-3, 12-15, 20-23, 24-27} / {4-7, 8-11, 16-19,
+// 28-31} (+32) and the 32-lane phases of the transpose read; scratch/r6/swizzle_search.py): dh 96 -- low two chunk bits ^= (4 - (row >> 2)) & 3
+// (attention.hip's dkv_swz<96>); dh 192 -- low three chunk bits ^= row bits (2, 3, 1).
+#ifndef CHADA_M32_RM
+#define CHADA_M32_RM 0
+#endif
+template <int DH>
+__device__ __forceinline__ int rm_swz(int row) {
+  if constexpr (DH == 192) return ((row >> 2) & 3) | (((row >> 1) & 1) << 2);
+  else return (4 - ((row >> 2) & 3)) & 3;
+}
+
 template <int DH, int CB, int NW>
 struct Cfg {
   static constexpr int KVT = (DH > 96 || KV32_AT_DH96) ? 32 : 64;   // keys per tile
@@ -141,7 +157,10 @@ __device__ __forceinline__ void fwd_tile(BufRsrc qb, bf16_t* __restrict__ dst, c
     if (MASKED && kb >= nkb) continue;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const bf16x8 kf = (CHADA_M32_ABL & 2) ? qf[0][(ks + kb) % KS] : lds_read8(sK + (kb * KS + ks) * 512 + l * 8);
+      bf16x8 kf;
+      if (CHADA_M32_ABL & 2) kf = qf[0][(ks + kb) % KS];
+      else if (CHADA_M32_RM) kf = lds_read8(sK + (kb * 32 + (l & 31)) * DH + ((2 * ks + hi) ^ rm_swz<DH>(l & 31)) * 8);   // (the swizzle sees row bits 1-3 only)
+      else kf = lds_read8(sK + (kb * KS + ks) * 512 + l * 8);
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb) {
         if (ks == 0)
@@ -238,11 +257,17 @@ __device__ __forceinline__ void fwd_tile(BufRsrc qb, bf16_t* __restrict__ dst, c
     }
     const int g = l >> 4, ii = l & 15;
     const bf16_t* vrow = sV + kp * DB * 512 + (4 * (g >> 1) + (ii >> 2)) * 32 + (g & 1) * 16 + (ii & 3) * 4;
+    // row-major stage: the lane's 8-byte piece of key row kp * 16 + 4 (g >> 1) + (ii >> 2) (and that + 8), chunk 4 db + 2 (g & 1) + ((ii & 3) >> 1)
+    const int trow = 4 * (g >> 1) + (ii >> 2), low2 = 2 * (g & 1) + ((ii & 3) >> 1);
 #pragma unroll
     for (int db = 0; db < DB; ++db) {
       bf16x8 vf;
       if (CHADA_M32_ABL & 2) {
         vf = qf[0][(db + kp) % KS];
+      } else if (CHADA_M32_RM) {
+        const bf16x4 lo = lds_read_tr4(sV + (kp * 16 + trow) * DH + ((4 * db + low2) ^ rm_swz<DH>(trow)) * 8 + (ii & 1) * 4);
+        const bf16x4 hi4 = lds_read_tr4(sV + (kp * 16 + trow + 8) * DH + ((4 * db + low2) ^ rm_swz<DH>(trow + 8)) * 8 + (ii & 1) * 4);
+        vf = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
       } else {
         const bf16x4 lo = lds_read_tr4(vrow + db * 512);
         const bf16x4 hi4 = lds_read_tr4(vrow + db * 512 + 8 * 32);
@@ -342,7 +367,12 @@ __global__ __launch_bounds__(64 * NW, (CB > 1 ? 1 : (DH <= 96 ? (KV32_AT_DH96 ? 
 #pragma unroll
   for (int i = 0; i < NRW; ++i) {
     const int r = w + NW * i;
-    if (r < NKR) {
+    if (CHADA_M32_RM) {   // piece r = 64 consecutive 16-byte chunks of the row-major K (r < NKR) / V image; source chunk un-swizzled
+      static_assert(!CHADA_M32_RM || C::NVR == NKR, "row-major stages: K and V tiles of equal size");
+      const int id = (r % NKR) * 64 + l, row = id / (DH / 8), ch = id % (DH / 8);
+      rec_row[i] = row;
+      rec_col[i] = (r < NKR ? D : 2 * D) + (ch ^ rm_swz<DH>(row)) * 8;
+    } else if (r < NKR) {
       rec_row[i] = (r / KS) * 32 + li;
       rec_col[i] = D + (r % KS) * 16 + hi * 8;
     } else {

@@ -1308,7 +1308,12 @@ def test_five_step_trajectory_vs_golden(mode):
         assert len(step.graphs) == 2   # frozen / thawed last layer
         step.close()
     named = dict(model.named_parameters())
-    np.testing.assert_allclose(named["momentum_backbone.norm.weight"].detach().float().cpu().numpy(), g["post::momentum_backbone.norm.weight"], atol=2e-5, rtol=0)
+    # element-wise on a small tensor: an entry of the student whose gradient's sign is bf16 noise sits up to 2 lr k off after step k, and the EMA
+    # teacher collects (1 - tau) of that per step: <= 0.01 * 2 lr * (1 + 2 + .. + 5) = 1.5e-4 for such an entry (3 of 192 at 5e-5 .. 9e-5 observed),
+    # everything else to fp32 round-off
+    dt = np.abs(named["momentum_backbone.norm.weight"].detach().float().cpu().numpy() - g["post::momentum_backbone.norm.weight"])
+    n_steps = int(g["steps"])
+    assert dt.max() <= 0.01 * 2.0 * float(g["lr"]) * n_steps * (n_steps + 1) / 2 + 1e-5 and (dt > 2e-5).mean() <= 0.05, (dt.max(), (dt > 2e-5).mean())
     d = np.abs(named["backbone.norm.weight"].detach().float().cpu().numpy() - g["post::backbone.norm.weight"])
     assert d.max() <= 2.1 * int(g["steps"]) * float(g["lr"]) and (d > 5e-4).mean() <= 0.10, (d.max(), (d > 5e-4).mean())
 
