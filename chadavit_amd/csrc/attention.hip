@@ -1224,6 +1224,96 @@ __device__ __forceinline__ void attn_dkv_tile(BufRsrc qg, BufRsrc dog, BufRsrc l
   bf16x8 qfr[R], dofr[R], dot[R], qtf[R];
 #pragma unroll
   for (int i = 0; i < RD; ++i) row_read(i, qfr[i], dofr[i]);
+#ifndef CHADA_DKV_PIPE
+#define CHADA_DKV_PIPE 0   // (built, bit-identical, 12 spilled registers, 1 360 against 1 203 us -- off; profiles/r06a_*)
+#endif
+  if constexpr (K2 == 2 && CBK == 2 && RD == 1 && CHADA_DKV_PIPE != 0 && 2 * KS >= 4 && DB >= 4) {
+    // dh 96 (round 6): the tile's two 32-query halves software-pipelined inside the wave, as in attn_dq_tile:
+    //     A0 | A1 + B0 | C0 + B1 | C1        (A = S, dP MFMAs; B = P = exp, dS, pack; C = dV += P^T dO, dK += dS^T Q MFMAs)
+    // Same arithmetic, same accumulation order (bit-identical dK / dV); the exponentials, compiled out, are 11 % of this kernel, its fragment reads 22 %.
+    f32x4 s[2][CBK][2], dp[2][CBK][2];
+    bf16x8 pf[2][CBK], dsf[2][CBK];
+    auto mma_a = [&](int k2, int st, int cur) {
+      const int q2 = st / KS, ks = st % KS;
+      if (!MASKED || 2 * k2 + q2 < nvq) {
+#pragma unroll
+        for (int cb = 0; cb < CBK; ++cb) {
+          s[k2][cb][q2] = (ks == 0) ? mfma16(qfr[cur], kf[cb][0], f32x4{0.f, 0.f, 0.f, 0.f}) : mfma16(qfr[cur], kf[cb][ks], s[k2][cb][q2]);
+          dp[k2][cb][q2] = (ks == 0) ? mfma16(dofr[cur], vf[cb][0], f32x4{0.f, 0.f, 0.f, 0.f}) : mfma16(dofr[cur], vf[cb][ks], dp[k2][cb][q2]);
+        }
+      }
+    };
+    auto valu_slice = [&](int k2, int step) {   // steps 0 .. 3: (q2, cb) = (step >> 1, step & 1); the step after packs
+      if (step < 2 * CBK) {
+        const int q2 = step >> 1, cb = step & 1, qb = 2 * k2 + q2;
+        if (MASKED && qb >= nvq) {
+          s[k2][cb][q2] = f32x4{0.f, 0.f, 0.f, 0.f};
+          dp[k2][cb][q2] = f32x4{0.f, 0.f, 0.f, 0.f};
+        } else if constexpr ((CHADA_BWD_ABL & 8) == 0) {
+          const f32x4 l4 = *reinterpret_cast<const f32x4*>(sL + qb * 16 + 4 * g) * LOG2E;
+          const f32x4 d4 = *reinterpret_cast<const f32x4*>(sD + qb * 16 + 4 * g);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float p = __builtin_amdgcn_exp2f(fmaf(s[k2][cb][q2][r], c, -l4[r]));
+            if (MASKED && (q0 * KVT + qb * 16 + 4 * g + r >= len)) p = 0.f;
+            s[k2][cb][q2][r] = p;
+            dp[k2][cb][q2][r] = p * (dp[k2][cb][q2][r] - d4[r]);
+          }
+        }
+      } else if (step == 2 * CBK) {
+#pragma unroll
+        for (int cb = 0; cb < CBK; ++cb) {
+          pf[k2][cb] = pack8(s[k2][cb][0], s[k2][cb][1]);
+          dsf[k2][cb] = pack8(dp[k2][cb][0], dp[k2][cb][1]);
+        }
+      }
+    };
+    // ---- A0
+#pragma unroll
+    for (int st = 0; st < 2 * KS; ++st) {
+      const int cur = st & 1;
+      row_read(st + 1, qfr[cur ^ 1], dofr[cur ^ 1]);   // (st + 1 == 2 KS: the first row pair of half 1)
+      __builtin_amdgcn_sched_barrier(0);
+      mma_a(0, st, cur);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- A1 beside B0
+#pragma unroll
+    for (int st = 0; st < 2 * KS; ++st) {
+      const int cur = st & 1;
+      if (st + 1 < 2 * KS) row_read(2 * KS + st + 1, qfr[cur ^ 1], dofr[cur ^ 1]);
+      else tr_read(0, 0, dot[0], qtf[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_a(1, st, cur);
+      valu_slice(0, st);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int st = 2 * KS; st <= 2 * CBK; ++st) valu_slice(0, st);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- C0 beside B1, then C1: one ring of two transposed pairs across both halves
+#pragma unroll
+    for (int dbg = 0; dbg < 2 * DB; ++dbg) {
+      const int k2 = dbg / DB, db = dbg % DB, cur = dbg & 1;
+      if (dbg + 1 < 2 * DB) tr_read((dbg + 1) / DB, (dbg + 1) % DB, dot[cur ^ 1], qtf[cur ^ 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!MASKED || 2 * k2 < nvq) {
+#pragma unroll
+        for (int cb = 0; cb < CBK; ++cb) {
+          dv[cb][db] = mfma16(dot[cur], pf[k2][cb], dv[cb][db]);
+          dk[cb][db] = mfma16(qtf[cur], dsf[k2][cb], dk[cb][db]);
+        }
+      }
+      if (k2 == 0) valu_slice(1, db);
+      __builtin_amdgcn_sched_barrier(0);
+      if (k2 == 0 && db == DB - 1) {
+#pragma unroll
+        for (int st = DB; st <= 2 * CBK; ++st) valu_slice(1, st);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int k2 = 0; k2 < K2; ++k2) {
     f32x4 s[CBK][2], dp[CBK][2];
@@ -1438,6 +1528,94 @@ __device__ __forceinline__ void attn_dq_tile(BufRsrc kg, BufRsrc vg, bf16_t* __r
   const int nvb = MASKED ? min(KVT / 16, (len - kt * KVT + 15) >> 4) : KVT / 16;
   bf16x8 kfr[2], vfr[2], ktf[3];
   row_read(0, kfr[0], vfr[0]);
+#ifndef CHADA_DQ_PIPE
+#define CHADA_DQ_PIPE 0   // (built, bit-identical, measured: 988 against 989 us on cfg2's global pass -- off; profiles/r06a_*)
+#endif
+  if constexpr (K2 == 2 && CB == 2 && CHADA_DQ_PIPE != 0 && 2 * KS >= 4 && DB >= 4 && DB % 3 == 0) {
+    // dh 96 (round 6, side builds with -DCHADA_DQ_PIPE=1 only): the two 32-key halves of the tile software-pipelined INSIDE the wave.  In the order
+    // [S, dP of half 0][exp / dS of half 0][dQ += of half 0][S, dP of half 1] ... every phase waits for the one before it; compiled out, the
+    // exponentials are 29 % of the kernel (990 -> 706 us).  Dealing them out behind the other half's MFMAs changes NOTHING (988 us): what they cost is
+    // their issue slots, not a wait -- the kernel is the sum of its instruction classes' issue costs (profiles/r06a_*).  The schedule:
+    //     A0 | A1 + B0 | C0 + B1 | C1        (A = S, dP MFMAs; B = exp, dS, pack; C = dQ += K^T dS MFMAs)
+    // the VALU work of a half is dealt out, one (query block, 16-key block) pair per step, behind the MFMAs of the other half's neighbouring phase.
+    // Same arithmetic and the same accumulation order as the unpipelined body (bit-identical dQ); both halves' scores live at once (+ 32 registers).
+    f32x4 s[2][CB][2], dp[2][CB][2];
+    bf16x8 dsf[2][CB];
+    auto mma_a = [&](int k2, int st, int cur) {
+      const int k1 = st / KS, ks = st % KS;
+      if (!MASKED || 2 * k2 + k1 < nvb) {
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+          s[k2][cb][k1] = (ks == 0) ? mfma16(kfr[cur], qf[cb][0], f32x4{0.f, 0.f, 0.f, 0.f}) : mfma16(kfr[cur], qf[cb][ks], s[k2][cb][k1]);
+          dp[k2][cb][k1] = (ks == 0) ? mfma16(vfr[cur], dof[cb][0], f32x4{0.f, 0.f, 0.f, 0.f}) : mfma16(vfr[cur], dof[cb][ks], dp[k2][cb][k1]);
+        }
+      }
+    };
+    auto valu_slice = [&](int k2, int step) {   // steps 0 .. 3: pair (cb, k1) = (step >> 1, step & 1); the step after the last pair packs
+      if (step < 2 * CB) {
+        const int cb = step >> 1, k1 = step & 1;
+        if (MASKED && 2 * k2 + k1 >= nvb) {
+          s[k2][cb][k1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        } else if constexpr ((CHADA_BWD_ABL & 8) == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float p = __builtin_amdgcn_exp2f(fmaf(s[k2][cb][k1][r], c, -L2[cb]));
+            if (MASKED && (kt * KVT + (2 * k2 + k1) * 16 + 4 * g + r >= len)) p = 0.f;
+            s[k2][cb][k1][r] = p * (dp[k2][cb][k1][r] - dl[cb]);  // dS (unscaled)
+          }
+        }
+      } else if (step == 2 * CB) {
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) dsf[k2][cb] = pack8(s[k2][cb][0], s[k2][cb][1]);
+      }
+    };
+    // ---- A0
+#pragma unroll
+    for (int st = 0; st < 2 * KS; ++st) {
+      const int cur = st & 1;
+      row_read(st + 1, kfr[cur ^ 1], vfr[cur ^ 1]);   // (st + 1 == 2 KS: the first row pair of half 1)
+      __builtin_amdgcn_sched_barrier(0);
+      mma_a(0, st, cur);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- A1 beside B0
+#pragma unroll
+    for (int st = 0; st < 2 * KS; ++st) {
+      const int cur = st & 1;
+      if (st + 1 < 2 * KS) {
+        row_read(2 * KS + st + 1, kfr[cur ^ 1], vfr[cur ^ 1]);
+      } else {
+        ktf[0] = tr_read(0, 0);
+        ktf[1] = tr_read(0, 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mma_a(1, st, cur);
+      valu_slice(0, st);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int st = 2 * KS; st <= 2 * CB; ++st) valu_slice(0, st);   // (whatever of B0 the steps above did not reach)
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- C0 beside B1, then C1; the transposed fragments run through one ring of three across both halves
+#pragma unroll
+    for (int dbg = 0; dbg < 2 * DB; ++dbg) {
+      const int k2 = dbg / DB, db = dbg % DB;
+      if (dbg + 2 < 2 * DB) ktf[(dbg + 2) % 3] = tr_read((dbg + 2) / DB, (dbg + 2) % DB);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!MASKED || 2 * k2 < nvb) {
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) dq[cb][db] = mfma16(ktf[dbg % 3], dsf[k2][cb], dq[cb][db]);
+      }
+      if (k2 == 0) valu_slice(1, db);
+      __builtin_amdgcn_sched_barrier(0);
+      if (k2 == 0 && db == DB - 1) {
+#pragma unroll
+        for (int st = DB; st <= 2 * CB; ++st) valu_slice(1, st);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int k2 = 0; k2 < K2; ++k2) {
     f32x4 s[CB][2], dp[CB][2];

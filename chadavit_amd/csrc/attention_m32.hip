@@ -17,7 +17,8 @@
 //   * LEAN = 1 additionally folds scale * log2 e into the Q fragments and the reference into the MFMA's C operand (no FMA left): same
 //     speed as LEAN = 2 on the hardware (392 vs 393 us at 1024 x 589 tokens) but a second bf16 rounding of Q -- not used.
 //
-// LDS image of a 64-key (dh 96) / 32-key (dh 192) tile, written by LDS-DMA (buffer_load ... lds, 1 KiB per wave-instruction):
+// LDS image of a 64-key (dh 96) / 32-key (dh 192) tile, written by LDS-DMA (buffer_load ... lds, 1 KiB per wave-instruction).  Since round 6
+// the ROW-MAJOR image of the tile (CHADA_M32_RM below: bit-identical results, -1 ... -5 % by shape); rounds 3-5 and CHADA_M32_RM=0:
 //   K record (kb, ks):  lane l = K[key kb*32 + (l & 31)][d = ks*16 + (l >> 5)*8 .. +7]  -> A operand of S^T, one conflict-free
 //                       ds_read_b128 at lane * 16;
 //   V record (kp, db):  V[keys kp*16 .. +15][d = db*32 .. +31] row-major (64-byte rows)   -> A operand of O^T by two
@@ -32,6 +33,10 @@
 #include "common.h"
 
 using namespace chada;
+
+#ifndef CHADA_AB_SWITCHES
+#define CHADA_AB_SWITCHES 0   // 1 (side builds only): kernels that were built, measured and not adopted, behind their switches
+#endif
 
 namespace {
 
@@ -82,7 +87,7 @@ __device__ __forceinline__ float half_sum(float v) {
 // 28-31} (+32) and the 32-lane phases of the transpose read; scratch/r6/swizzle_search.py): dh 96 -- low two chunk bits ^= (4 - (row >> 2)) & 3
 // (attention.hip's dkv_swz<96>); dh 192 -- low three chunk bits ^= row bits (2, 3, 1).
 #ifndef CHADA_M32_RM
-#define CHADA_M32_RM 0
+#define CHADA_M32_RM 1   // (0: the fragment-major records of rounds 3-5 -- bit-identical results; same-box A/B in profiles/r06a_*)
 #endif
 template <int DH>
 __device__ __forceinline__ int rm_swz(int row) {
@@ -124,7 +129,8 @@ __device__ __forceinline__ WorkItem decode_work(const int* __restrict__ work, in
 // row maximum, which becomes the fixed reference held in `minit` = -m);  MODE 2: diet steady state (no max, no FMA, no rescale).
 // In MODE 1 / 2 the Q fragments carry the scale (c == 1 is passed).
 #ifndef CHADA_M32_ABL
-#define CHADA_M32_ABL 0   // timing-only ablations of the unpaired kernel (wrong results): 1 = no refills, 2 = no fragment reads, 8 = no softmax
+#define CHADA_M32_ABL 0   // timing-only ablations of the unpaired kernel (wrong results): 1 = no refills, 2 = no fragment reads, 8 = no softmax,
+                          // 16 = refills issued but never waited for, 32 = every refill fetches key tile 0 (the same L2-hot lines)
 #endif
 template <int DH, int CB, int NW, int MODE, bool MASKED>
 __device__ __forceinline__ void fwd_tile(BufRsrc qb, bf16_t* __restrict__ dst, const bf16_t* __restrict__ sK, bool issue, int kt, int len,
@@ -137,7 +143,7 @@ __device__ __forceinline__ void fwd_tile(BufRsrc qb, bf16_t* __restrict__ dst, c
   if (issue && (CHADA_M32_ABL & 1) == 0) {
 #pragma unroll
     for (int i = 0; i < NRW; ++i) {
-      const unsigned off = (unsigned)min((kt + 1) * KVT + rec_row[i], len - 1) * ldu + rec_col[i];
+      const unsigned off = (unsigned)min(((CHADA_M32_ABL & 32) ? 0 : (kt + 1) * KVT) + rec_row[i], len - 1) * ldu + rec_col[i];
       lds_dma16(qb, dst + (w + NW * i) * 512, off * 2, 0);
     }
   }
@@ -280,6 +286,8 @@ __device__ __forceinline__ void fwd_tile(BufRsrc qb, bf16_t* __restrict__ dst, c
 }
 
 // All key tiles of one work item for this block.  Returns with o / m / ls final.
+#define M32_TILE_BARRIER() do { if (CHADA_M32_ABL & 16) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
+                                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); } while (0)
 template <int DH, int CB, int NW, int LEAN>
 __device__ __forceinline__ void fwd_item(BufRsrc qrs, bf16_t* smem, int len, int qrow0, unsigned ldu, float c, int w, int l,
                                          const int (&rec_row)[Cfg<DH, CB, NW>::NRW], const unsigned (&rec_col)[Cfg<DH, CB, NW>::NRW],
@@ -305,20 +313,20 @@ __device__ __forceinline__ void fwd_item(BufRsrc qrs, bf16_t* smem, int len, int
   }
   constexpr int M_FIRST = LEAN ? 1 : 0, M_REST = LEAN == 1 ? 2 : (LEAN == 2 ? 4 : 0);
   if (nkt == 1) {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    M32_TILE_BARRIER();
     fwd_tile<DH, CB, NW, M_FIRST, true>(qrs, smem + STAGE, smem, false, 0, len, qrow0, ldu, c, w, l, rec_row, rec_col, qf, o, m, ls, minit);
     return;
   }
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  M32_TILE_BARRIER();
   fwd_tile<DH, CB, NW, M_FIRST, false>(qrs, smem + STAGE, smem, true, 0, len, qrow0, ldu, c, w, l, rec_row, rec_col, qf, o, m, ls, minit);
   for (int kt = 1; kt < nkt - 1; ++kt) {
     // tile kt has landed (LDS-DMA completion is visible only through the issuing wave's vmcnt) and everybody is done reading
     // the other stage
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    M32_TILE_BARRIER();
     fwd_tile<DH, CB, NW, M_REST, false>(qrs, smem + ((kt + 1) & 1) * STAGE, smem + (kt & 1) * STAGE, true, kt, len, qrow0, ldu, c, w, l, rec_row,
                                         rec_col, qf, o, m, ls, minit);
   }
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  M32_TILE_BARRIER();
   fwd_tile<DH, CB, NW, M_REST, true>(qrs, smem + (nkt & 1) * STAGE, smem + ((nkt - 1) & 1) * STAGE, false, nkt - 1, len, qrow0, ldu, c, w, l,
                                      rec_row, rec_col, qf, o, m, ls, minit);
 }
@@ -438,6 +446,7 @@ __global__ __launch_bounds__(64 * NW, (CB > 1 ? 1 : (DH <= 96 ? (KV32_AT_DH96 ? 
   }
 }
 
+#if CHADA_AB_SWITCHES
 // =====================================================================================
 // The paired ("ping-pong") schedule on 32x32x16 bodies, head widths 96 and 192 with the factory's TWO heads (round 6).
 //
@@ -451,8 +460,13 @@ __global__ __launch_bounds__(64 * NW, (CB > 1 ? 1 : (DH <= 96 ? (KV32_AT_DH96 ? 
 // K(t+2) replaces K(t), last read in this half's X_t; V(t+1) replaces V(t-1), last read in X_t), a wave waits for its own pieces at the end of
 // its next X segment, the barrier behind it publishes them.  The last key tile multiplies only the 32-key blocks that hold a valid key (block-
 // uniform choice between two straight-line segment bodies, no branch inside an MFMA stream); its masked scores are -inf -> P = 0 exactly.
-// A row that leaves the fixed-reference softmax's range re-runs its half with attn_fwd_m32_kernel's own textbook loop (fwd_item<.., 0>) while
-// the other half keeps the barrier count.
+// A row that leaves the fixed-reference softmax's range makes the block run the loop a second time, that half with the running-max recurrence.
+//
+// MEASURED (round 6, profiles/r06a_*), bit-identical to the unpaired kernel on every shape incl. the re-run, and NOT ADOPTED -- a side-build kernel
+// (-DCHADA_AB_SWITCHES=1, variant 6 / CHADAVIT_ATTN_FWD_PAIR32=1): cfg2's global pass 862 against 745 us (+15 %), local crops +26 %, dh 192 global
+// 588-609 against 607 (-3 ... 0 %, with s_setprio 1 for the second half), dh 192 local +9 %.  Why: one 512-thread block per CU leaves nothing beside a
+// block's prologue and epilogue (5.4 us of a 14.7 us block at 589 tokens; MFMAs + barriers alone: 590 us), which three independent 4-wave blocks
+// per CU cover for one another; at 10 key tiles per item the schedule inside the loop cannot pay that back.
 // =====================================================================================
 #ifndef CHADA_P32_PD
 #define CHADA_P32_PD 2      // fragments requested this many steps ahead of their MFMA
@@ -761,6 +775,8 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pair32_kernel(const bf16_t* _
   if (hi == 0 && qrow < len) lse[(size_t)h * T + seq0 + qrow] = (m[0] + log2f(lt)) * LN2;
 }
 
+#endif  // CHADA_AB_SWITCHES
+
 }  // namespace
 
 // variant: 0 / 5 = lean softmax on exact scores (what chadavit_attn_fwd dispatches to), 1 = textbook online softmax, 2 = lean softmax with
@@ -777,6 +793,7 @@ extern "C" int chadavit_attn_fwd_m32(const chada_bf16* qkv_, chada_bf16* out_, f
 #define M32_LAUNCH(DHV, CBV, NWV, LEANV)                                                                                              \
   hipLaunchKernelGGL((attn_fwd_m32_kernel<DHV, CBV, NWV, LEANV>), dim3(n_work * (TILE / (NWV * 32 * CBV)) * H), dim3(64 * NWV), 0, s, qkv, out, \
                      lse, cu_seqlens, work, T, D, H, scale)
+#if CHADA_AB_SWITCHES
   // the paired schedule (two heads of one 128-row tile per 512-thread block): CHADAVIT_ATTN_FWD_PAIR32=1 or variant 6
   static const int pair32 = getenv("CHADAVIT_ATTN_FWD_PAIR32") ? atoi(getenv("CHADAVIT_ATTN_FWD_PAIR32")) : 0;
   if (H == 2 && (dh == 96 || dh == 192) && (variant == 6 || (variant == 0 && pair32 > 0))) {
@@ -785,6 +802,7 @@ extern "C" int chadavit_attn_fwd_m32(const chada_bf16* qkv_, chada_bf16* out_, f
     CHADA_CHECK_LAUNCH();
     return 0;
   }
+#endif
   const int lean = variant == 1 ? 0 : (variant == 2 ? 1 : 2);
   if (dh == 96) {
     if (lean == 0) M32_LAUNCH(96, 1, 4, 0);

@@ -65,6 +65,34 @@ __device__ __forceinline__ i32x8 mx8_frag(const uint8_t* __restrict__ st, unsign
   const u32x4 a1 = *reinterpret_cast<const u32x4*>(st + a1_addr);
   return i32x8{(int)a0[0], (int)a0[1], (int)a0[2], (int)a0[3], (int)a1[0], (int)a1[1], (int)a1[2], (int)a1[3]};
 }
+// MX_PINGPONG (round 6): the two consumer waves of every SIMD (w and w + 4) in COMPLEMENTARY segments, two barriers per k-tile -- one reads the
+// k-tile's fragments and scales into registers (Y) while the other multiplies the ones it read a segment earlier (X: 16 MFMAs, nothing else).  As built
+// (one barrier per k-tile) all eight waves read, then all multiply: 1 470 cycles per k-tile for 1 024 of matrix work (profiles/r03f_mx8_gemm.md).
+#ifndef MX_PINGPONG
+#define MX_PINGPONG 0
+#endif
+struct Mx8Frags {
+  i32x8 af[4], bfr[4];
+  int sa[4], sb[4];
+};
+__device__ __forceinline__ void mx8_read(const uint8_t* __restrict__ st, const unsigned (&a_addr)[2], const unsigned (&b_addr)[2], unsigned sa_addr,
+                                         unsigned sb_addr, Mx8Frags& f) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    f.bfr[t] = mx8_frag(st, b_addr[0] + t * 2048, b_addr[1] + t * 2048);
+    f.sa[t] = st[MX_WS + sa_addr + t * 16];
+    f.sb[t] = st[MX_XS + sb_addr + t * 16];
+    f.af[t] = mx8_frag(st, MX_XT + a_addr[0] + t * 2048, MX_XT + a_addr[1] + t * 2048);
+  }
+}
+__device__ __forceinline__ void mx8_mma(const Mx8Frags& f, f32x4 (&acc)[4][4]) {
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+      acc[nt][mt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(f.af[nt], f.bfr[mt], acc[nt][mt], 0, 0, 0, f.sa[nt], 0, f.sb[mt]);
+}
+
 template <bool STREAM_A>
 __device__ __forceinline__ void mx8_consume(const uint8_t* __restrict__ st, const unsigned (&a_addr)[2], const unsigned (&b_addr)[2],
                                             unsigned sa_addr, unsigned sb_addr, f32x4 (&acc)[4][4]) {
@@ -187,7 +215,9 @@ __global__ __launch_bounds__((MX_NCONS + MX_NPROD) * 64, 3) void gemm_mx8_kernel
       else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
       if (q + 2 < Q) issue_next(smem_o + st_wr * MX_STAGE);
       st_wr = st_wr == MX_NSTG - 1 ? 0 : st_wr + 1;
+      if (MX_PINGPONG) asm volatile("s_barrier" ::: "memory");   // the odd slot of position q (second half's fragment reads)
     }
+    if (MX_PINGPONG) asm volatile("s_barrier" ::: "memory");     // slot 2 Q: the second half's last matrix segment
     return;
   }
 
@@ -213,10 +243,10 @@ __global__ __launch_bounds__((MX_NCONS + MX_NPROD) * 64, 3) void gemm_mx8_kernel
   constexpr bool AUXR = EPI == MXE_RESID || EPI == MXE_RELUMASK;   // the epilogue reads an [M, N] bf16 operand (residual / ReLU pattern)
   bf16x8 ep_rr[AUXR ? 4 : 1][2];   // its rows for the tile about to finish (see the prefetch below)
   int st_rd = 0, ckt = 0, ctile = 0;
-  for (int q = 0; q < Q; ++q) {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // B_q
+  // the residual / ReLU-pattern rows of output tile `ctile` are requested behind the barrier of its last k-step and land behind that step's MFMAs.
+  // The epilogue then issues no load at all: a load's wait also waits for every OLDER store.
+  auto aux_prefetch = [&]() {
     if constexpr (AUXR) {
-      if (ckt == KT - 1) {
         // last k-step of output tile `ctile`: its residual rows are requested now and land behind this step's MFMAs.  The epilogue
         // then issues no load at all: a load's wait also waits for every OLDER store.
         const int bid = mx_xcd_remap((int)blockIdx.x + ctile * (int)gridDim.x, n_tiles);
@@ -229,11 +259,9 @@ __global__ __launch_bounds__((MX_NCONS + MX_NPROD) * 64, 3) void gemm_mx8_kernel
 #pragma unroll
           for (int k = 0; k < 2; ++k)   // the epilogue's own layout: row (r & 7) + 8 k of the slab, columns 32 r3 + 8 g + [0, 8); rows past M read 0
             ep_rr[mt][k] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(aux_rs, aux_voff, (mt * 16 + 8 * k) * a.ldaux * 2, 0));
-      }
     }
-    const uint8_t* const stg = smem_o + st_rd * MX_STAGE;
-    mx8_consume<AUXR>(stg, a_addr, b_addr, sa_addr, sb_addr, acc);
-    if (++ckt == KT) {
+  };
+  auto epilogue = [&](const uint8_t* stg) {
       // ---- epilogue of output tile `ctile`, per wave, no LDS and no barrier.  acc[nt][mt][i] = out[m = .. + mt*16 + r][n = .. +
       // nt*16 + 4 g + i]: written straight out that is 8-byte pieces scattered over 16 rows per instruction.  The four lanes
       // (r, g = 0..3) hold 64 consecutive n of row r between them; two rounds of register <-> lane-bit exchanges (v_permlane32_swap:
@@ -243,10 +271,10 @@ __global__ __launch_bounds__((MX_NCONS + MX_NPROD) * 64, 3) void gemm_mx8_kernel
       // 15 400 cycles a tile took.)
       const int bid = mx_xcd_remap((int)blockIdx.x + ctile * (int)gridDim.x, n_tiles);
       const int m0 = (bid / tiles_n) * MX_BM, n0 = (bid % tiles_n) * MX_BN;
-      f32x4 bia[4];   // bias of the lane's accumulator columns (added before the exchange: the exchange below is inline asm, and its
+      f32x4 bia[4];   // (MX_PINGPONG: the bias is the accumulators' initial value -- bias_init below -- and nothing is added here)   // bias of the lane's accumulator columns (added before the exchange: the exchange below is inline asm, and its
                       // inputs then come from a VALU instruction hipcc itself has placed after the MFMAs)
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) bia[nt] = *reinterpret_cast<const f32x4*>(stg + MX_BIAS + (wn * 64 + 16 * nt + 4 * g) * 4);
+      for (int nt = 0; nt < 4; ++nt) bia[nt] = MX_PINGPONG ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(stg + MX_BIAS + (wn * 64 + 16 * nt + 4 * g) * 4);
       // ONE wait for the prefetched residual rows, here, before the first store (these empty statements "use" them): left to
       // itself hipcc waits for row k at slab k with a count that ignores the conditional stores in between, and every such wait
       // drains the stores of the slabs before it
@@ -349,6 +377,58 @@ __global__ __launch_bounds__((MX_NCONS + MX_NPROD) * 64, 3) void gemm_mx8_kernel
           }
         }
       }
+  };
+  if constexpr (MX_PINGPONG != 0) {
+    // ---- two barriers per stream position q.  Slot 2q: half A (waves 0-3) reads position q into registers, half B (waves 4-7; wave w and w + 4 share a
+    // SIMD) multiplies position q - 1; slot 2q + 1: A multiplies q, B reads q.  A stage is read in slots 2q and 2q + 1 and refilled (position q + 3) behind
+    // the barrier of slot 2q + 2 -- so neither half may touch it later than that: the bias of an output tile is taken as the accumulators' INITIAL value
+    // when the tile's first position is read (it rides every k-tile), and half A's epilogue, which would otherwise idle the SIMD for a whole slot of its
+    // own, runs at the head of slot 2q + 2 beside half B's last matrix segment and epilogue.
+    const bool halfB = w >= 4;
+    Mx8Frags fr;
+    auto read_pos = [&](int q) {
+      const uint8_t* const stg = smem_o + (q % MX_NSTG) * MX_STAGE;
+      mx8_read(stg, a_addr, b_addr, sa_addr, sb_addr, fr);
+      if (q % KT == 0) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(stg + MX_BIAS + (wn * 64 + 16 * nt + 4 * g) * 4);
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = bv;
+        }
+      }
+    };
+    if (!halfB) {
+      for (int q = 0; q < Q; ++q) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // slot 2q
+        if (q > 0 && q % KT == 0) { epilogue(nullptr); ++ctile; }
+        read_pos(q);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // slot 2q + 1
+        if (q % KT == KT - 1) aux_prefetch();
+        mx8_mma(fr, acc);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // slot 2Q
+      epilogue(nullptr);
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // slot 0
+      for (int q = 0; q < Q; ++q) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // slot 2q + 1
+        read_pos(q);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // slot 2q + 2
+        if (q % KT == KT - 1) aux_prefetch();
+        mx8_mma(fr, acc);
+        if (q % KT == KT - 1) { epilogue(nullptr); ++ctile; }
+      }
+    }
+    return;
+  }
+  for (int q = 0; q < Q; ++q) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // B_q
+    if (ckt == KT - 1) aux_prefetch();
+    const uint8_t* const stg = smem_o + st_rd * MX_STAGE;
+    mx8_consume<AUXR>(stg, a_addr, b_addr, sa_addr, sb_addr, acc);
+    if (++ckt == KT) {
+      epilogue(stg);
       ckt = 0;
       ++ctile;
     }

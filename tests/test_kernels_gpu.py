@@ -379,6 +379,31 @@ torch.save(outs, %r)
         assert torch.equal(dqkv.cpu().view(torch.int16), old[i][2].view(torch.int16)) and torch.equal(delta.cpu(), old[i][3]), (nch, p)
 
 
+def test_attention_fwd_row_major_stages_and_paired_schedule_are_bit_identical_to_the_fragment_major_kernel():
+    """Round 6.  (a) The 32x32x16 forward stages its K / V tiles as row-major images since this round (CHADA_M32_RM = 1: whole-row pieces per LDS-DMA
+    instruction, chunks XOR-swizzled on the source side); a side build with the fragment-major records of rounds 3-5 (-DCHADA_M32_RM=0) must give the
+    same outputs and LSE BIT FOR BIT on ragged batches at dh 96 / 192 incl. the lean softmax's re-run (a spiked score), single-tile and edge-length
+    sequences.  (b) The paired (ping-pong) forward -- two heads per 512-thread block, the halves one segment apart; built, measured, not adopted: a
+    side-build kernel, variant 6 of chadavit_attn_fwd_m32 -- must reproduce the unpaired kernel bit for bit, re-run included."""
+    import subprocess, sys, os
+    from chadavit_amd.build import build, build_ab
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fm = build(verbose=False, side="m32fm", extra_flags=["-DCHADA_M32_RM=0"], units=("attention_m32.hip",))
+    dumps = []
+    for lib in (None, fm):
+        env = dict(os.environ) if lib is None else dict(os.environ, CHADAVIT_HIP_LIB=lib, CHADAVIT_ALLOW_FOREIGN_LIB="1")
+        r = subprocess.run([sys.executable, os.path.join(root, "scratch", "r6", "fwd_dump.py")], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        dumps.append([ln for ln in r.stdout.splitlines() if ln and ln[0].isdigit()])
+    assert len(dumps[0]) == 22 and dumps[0] == dumps[1], [(a, b) for a, b in zip(*dumps) if a != b][:4]
+    assert all(ln.endswith("True") for ln in dumps[0])   # finite everywhere
+    r = subprocess.run([sys.executable, os.path.join(root, "scratch", "r6", "p32_time.py"), "check"], capture_output=True, text=True, timeout=900, cwd=root,
+                       env=dict(os.environ, CHADAVIT_HIP_LIB=build_ab(), CHADAVIT_ALLOW_FOREIGN_LIB="1"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if "identical=" in ln]
+    assert len(lines) == 18 and all("identical=True" in ln for ln in lines), [ln for ln in lines if "identical=True" not in ln]
+
+
 def test_attention_fwd_row_major_stages():
     """A forward instance of the A/B side build (not in the product library), kept for its measurement (profiles/r05o_*): the 16x16x32 forward on
     ROW-MAJOR LDS stages (CHADAVIT_ATTN_FWD_RM=1: whole 128-byte lines per LDS-DMA instruction, chunks swizzled on the source side; the switch is read
