@@ -146,6 +146,9 @@ constexpr int MX_BIAS = MX_WS + 512;                        // the tile's 128 bi
 template <int EPI>
 __global__ __launch_bounds__((MX_NCONS + MX_NPROD) * 64, 3) void gemm_mx8_kernel(Mx8Args a) {
   __shared__ __attribute__((aligned(16))) uint8_t smem[MX_NSTG * MX_STAGE];
+  // (the instances whose epilogue holds 32 registers of residual / ReLU-pattern rows across the last matrix segment do not fit the ping-pong
+  // schedule's whole-k-tile fragment set in 168 registers -- 60 spilled --: they keep one barrier per k-tile)
+  constexpr bool PP = MX_PINGPONG != 0 && !(EPI == MXE_RESID || EPI == MXE_RELUMASK);
   const int tid = threadIdx.x, l = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int M = a.M, N = a.N, K = a.K;
@@ -215,9 +218,9 @@ __global__ __launch_bounds__((MX_NCONS + MX_NPROD) * 64, 3) void gemm_mx8_kernel
       else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
       if (q + 2 < Q) issue_next(smem_o + st_wr * MX_STAGE);
       st_wr = st_wr == MX_NSTG - 1 ? 0 : st_wr + 1;
-      if (MX_PINGPONG) asm volatile("s_barrier" ::: "memory");   // the odd slot of position q (second half's fragment reads)
+      if (PP) asm volatile("s_barrier" ::: "memory");   // the odd slot of position q (second half's fragment reads)
     }
-    if (MX_PINGPONG) asm volatile("s_barrier" ::: "memory");     // slot 2 Q: the second half's last matrix segment
+    if (PP) asm volatile("s_barrier" ::: "memory");     // slot 2 Q: the second half's last matrix segment
     return;
   }
 
@@ -274,7 +277,7 @@ __global__ __launch_bounds__((MX_NCONS + MX_NPROD) * 64, 3) void gemm_mx8_kernel
       f32x4 bia[4];   // (MX_PINGPONG: the bias is the accumulators' initial value -- bias_init below -- and nothing is added here)   // bias of the lane's accumulator columns (added before the exchange: the exchange below is inline asm, and its
                       // inputs then come from a VALU instruction hipcc itself has placed after the MFMAs)
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) bia[nt] = MX_PINGPONG ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(stg + MX_BIAS + (wn * 64 + 16 * nt + 4 * g) * 4);
+      for (int nt = 0; nt < 4; ++nt) bia[nt] = PP ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(stg + MX_BIAS + (wn * 64 + 16 * nt + 4 * g) * 4);
       // ONE wait for the prefetched residual rows, here, before the first store (these empty statements "use" them): left to
       // itself hipcc waits for row k at slab k with a count that ignores the conditional stores in between, and every such wait
       // drains the stores of the slabs before it
@@ -378,7 +381,7 @@ __global__ __launch_bounds__((MX_NCONS + MX_NPROD) * 64, 3) void gemm_mx8_kernel
         }
       }
   };
-  if constexpr (MX_PINGPONG != 0) {
+  if constexpr (PP) {
     // ---- two barriers per stream position q.  Slot 2q: half A (waves 0-3) reads position q into registers, half B (waves 4-7; wave w and w + 4 share a
     // SIMD) multiplies position q - 1; slot 2q + 1: A multiplies q, B reads q.  A stage is read in slots 2q and 2q + 1 and refilled (position q + 3) behind
     // the barrier of slot 2q + 2 -- so neither half may touch it later than that: the bias of an output tile is taken as the accumulators' INITIAL value
