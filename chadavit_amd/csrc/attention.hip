@@ -1492,6 +1492,11 @@ __device__ __forceinline__ void attn_dq_tile(BufRsrc kg, BufRsrc vg, bf16_t* __r
   constexpr int KVT = (DH > 96) ? 32 : 64, K2 = KVT / 32;
   constexpr int NRW = KVT * (DH / 8) / (64 * NW);
   constexpr int TILE_E = KVT * DH;
+#ifndef CHADA_DQ_FOLD_DELTA
+#define CHADA_DQ_FOLD_DELTA 1   // (round 6: dQ 977 -> 953 us at cfg2's global pass, 880 -> 874 at dh 192; one VALU op of ~4.5 per score less.  dh 384 keeps the
+                                // subtraction: its dQ is held bit-identical to the fragment-major kernel it replaced)
+#endif
+  constexpr bool FOLD = CHADA_DQ_FOLD_DELTA != 0 && DH <= 192;
   const int g = l >> 4;
   int li = l & 15;
   if constexpr (NW == 8) asm volatile("" : "+v"(li));   // (dh 384, 192 registers of Q / dO / dQ state: keeps the tile's swizzled fragment addresses from being hoisted out of the tile loop)
@@ -1633,7 +1638,9 @@ __device__ __forceinline__ void attn_dq_tile(BufRsrc kg, BufRsrc vg, bf16_t* __r
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) {
           s[cb][k1] = (ks == 0) ? mfma16(kfr[cur], qf[cb][0], f32x4{0.f, 0.f, 0.f, 0.f}) : mfma16(kfr[cur], qf[cb][ks], s[cb][k1]);
-          dp[cb][k1] = (ks == 0) ? mfma16(vfr[cur], dof[cb][0], f32x4{0.f, 0.f, 0.f, 0.f}) : mfma16(vfr[cur], dof[cb][ks], dp[cb][k1]);
+          // (CHADA_DQ_FOLD_DELTA: delta enters as the accumulator's initial value -- dP - delta comes out of the MFMAs, one VALU op per score less)
+          dp[cb][k1] = (ks == 0) ? mfma16(vfr[cur], dof[cb][0], FOLD ? f32x4{-dl[cb], -dl[cb], -dl[cb], -dl[cb]} : f32x4{0.f, 0.f, 0.f, 0.f})
+                                 : mfma16(vfr[cur], dof[cb][ks], dp[cb][k1]);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -1652,7 +1659,7 @@ __device__ __forceinline__ void attn_dq_tile(BufRsrc kg, BufRsrc vg, bf16_t* __r
         for (int r = 0; r < 4; ++r) {
           float p = __builtin_amdgcn_exp2f(fmaf(s[cb][k1][r], c, -L2[cb]));
           if (MASKED && (kt * KVT + (2 * k2 + k1) * 16 + 4 * g + r >= len)) p = 0.f;
-          s[cb][k1][r] = p * (dp[cb][k1][r] - dl[cb]);  // dS (unscaled)
+          s[cb][k1][r] = FOLD ? p * dp[cb][k1][r] : p * (dp[cb][k1][r] - dl[cb]);  // dS (unscaled)
         }
       }
       dsf[cb] = pack8(s[cb][0], s[cb][1]);
