@@ -1476,6 +1476,225 @@ __global__ __launch_bounds__(256, (DH > 192 ? 1 : 2)) void attn_bwd_dkv_dma_kern
   }
 }
 
+#if CHADA_AB_SWITCHES
+// =====================================================================================
+// dK / dV at dh = 96 on the PAIRED schedule (round 6; side builds only: CHADAVIT_ATTN_DKV_PAIR=1).  One 512-thread block per (image, 128-key tile): half A
+// (waves 0-3) runs head 0, half B (waves 4-7) head 1 -- wave w and w + 4 share a SIMD --, both the arithmetic of attn_bwd_dkv_dma_kernel<96, 2> (same
+// fragments, same order of accumulation: bit-identical dK / dV), cut into two segments per 32-query HALF-tile and held one segment apart by the block's barriers:
+//   X_h (matrix):          dV += P(h-1)^T dO, dK += dS(h-1)^T Q   then   S(h) = Q K^T, dP(h) = dO V^T      -- 48 MFMAs and their fragment reads
+//   Y_h (everything else): the LDS-DMA requests of a later query tile, then P(h) = exp2(..), dS(h) = P (dP - delta), packed to bf16
+// Per half: a ring of THREE row-major swizzled stages (Q tile | dO tile | lse | delta of 64 queries; the transposed reads of X_h still need tile (h-1)/2
+// while the row reads are already in tile h/2): query tile t + 2 is requested in Y_2t into the stage of tile t - 1, every wave waits for its own pieces at
+// the end of each matrix segment.  Four barriers per 64-query tile instead of one.
+// =====================================================================================
+template <int DH>
+__global__ __launch_bounds__(512, 1) void attn_bwd_dkv_pair_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                                   const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                   bf16_t* __restrict__ dqkv, const int* __restrict__ cu,
+                                                                   const int* __restrict__ work, int T, int D, float scale) {
+  constexpr int CBK = 2, KS = DH / 32, DB = DH / 16, KVT = 64, NRW = KVT * (DH / 8) / 256;
+  constexpr int TILE_E = KVT * DH, STAGE = 2 * TILE_E + 4 * KVT, HALF = 3 * STAGE;
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * HALF];
+  const int tid = threadIdx.x, l = tid & 63, g = l >> 4, li = l & 15;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = w >> 2, wk = w & 3;
+  const int b = work[2 * blockIdx.x], kt = work[2 * blockIdx.x + 1];
+  if (b < 0) return;
+  const int seq0 = cu[b], len = cu[b + 1] - seq0;
+  if (kt * TILE >= len) return;
+  const size_t ld = 3 * (size_t)D;
+  const bf16_t* qbase = qkv + (size_t)seq0 * ld + h * DH;
+  const bf16_t* kbase = qbase + D;
+  const bf16_t* vbase = qbase + 2 * D;
+  const bf16_t* dobase = dout + (size_t)seq0 * D + h * DH;
+  const float c = scale * LOG2E;
+  int krow[CBK];
+  bf16x8 kf[CBK][KS], vf[CBK][KS];
+#pragma unroll
+  for (int cb = 0; cb < CBK; ++cb) {
+    krow[cb] = kt * TILE + wk * 16 * CBK + cb * 16 + li;
+    const int kr = min(krow[cb], len - 1);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      kf[cb][ks] = *reinterpret_cast<const bf16x8*>(kbase + (size_t)kr * ld + ks * 32 + g * 8);
+      vf[cb][ks] = *reinterpret_cast<const bf16x8*>(vbase + (size_t)kr * ld + ks * 32 + g * 8);
+    }
+  }
+  f32x4 dk[CBK][DB], dv[CBK][DB];
+#pragma unroll
+  for (int cb = 0; cb < CBK; ++cb)
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+      dk[cb][db] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dv[cb][db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  const unsigned ldq = 3u * (unsigned)D, ldo = (unsigned)D;
+  const int nqt = (len + KVT - 1) / KVT, NH = 2 * nqt;   // 32-query half-tiles
+  const BufRsrc qrs = make_rsrc(qbase), dors = make_rsrc(dobase), lrs = make_rsrc(lse + (size_t)h * T + seq0), drs = make_rsrc(delta + (size_t)h * T + seq0);
+  const bool idle = kt * TILE + wk * 16 * CBK >= len;
+  const int nvq_last = min(KVT / 16, (len - (nqt - 1) * KVT + 15) >> 4);   // valid 16-query blocks of the last tile
+  int opq = 0;
+  asm volatile("" : "+s"(opq));
+  bf16_t* const base = smem + h * HALF + opq;
+  auto fetch = [&](int t, bf16_t* __restrict__ dst) {   // this wave's pieces of query tile t
+    const int r0 = t * KVT;
+    int lx = l;
+    asm volatile("" : "+v"(lx));   // (the pieces' row / chunk are recomputed per tile instead of living in 14 registers across the loop: 244 of 256 are taken)
+#pragma unroll
+    for (int i = 0; i < NRW; ++i) {
+      const int id = (wk + 4 * i) * 64 + lx, rrow = id / (DH / 8), ch = id % (DH / 8);
+      const unsigned col = (unsigned)((ch ^ dkv_swz<DH>(rrow)) * 8);
+      const unsigned row = (unsigned)min(r0 + rrow, len - 1);
+      lds_dma16(qrs, dst + (wk + 4 * i) * 512, (row * ldq + col) * 2, 0);
+      lds_dma16(dors, dst + TILE_E + (wk + 4 * i) * 512, (row * ldo + col) * 2, 0);
+    }
+    if (wk == 0 && l < KVT) {
+      const int qr = min(r0 + l, len - 1);
+      lds_dma4(lrs, dst + 2 * TILE_E, qr * 4, 0);
+      lds_dma4(drs, dst + 2 * TILE_E + 2 * KVT, qr * 4, 0);
+    }
+  };
+  f32x4 s[CBK][2], dp[CBK][2];
+  bf16x8 pf[CBK], dsf[CBK];
+  // ---- X: [C of half hc (transposed reads out of stage sC), A of half ha (row reads out of stage sA)]; nvq_* = that half's tile's valid query blocks
+  auto seg_x = [&](const bf16_t* __restrict__ sC, int k2c, int nvq_c, const bf16_t* __restrict__ sA, int k2a, int nvq_a, auto do_c_tag, auto do_a_tag) {
+    constexpr bool DO_C = decltype(do_c_tag)::value, DO_A = decltype(do_a_tag)::value;
+    // (the last query tile's masks are run-time conditions here; five compile-time instantiations of the two segment bodies instead -- unconditional
+    // MFMAs everywhere but in the last tile -- spill 213 registers, this form 51: the unpaired kernel's state alone is 244 of the 256 registers)
+    if (idle) return;
+    int li = l & 15, g = l >> 4;
+    asm volatile("" : "+v"(li), "+v"(g));   // (keeps the segment's swizzled fragment addresses from being hoisted out of the half-tile loop: 64 spilled registers otherwise)
+    if constexpr (DO_C) {
+      const bf16_t* sQ = sC;
+      const bf16_t* sO = sC + TILE_E;
+      bf16x8 dot[2], qtf[2];
+      auto tr_read = [&](int db, bf16x8& d_, bf16x8& q_) {
+        const int trow = k2c * 32 + 4 * g + (li >> 2);
+        const int ch = (2 * db + ((li & 3) >> 1)) ^ dkv_swz<DH>(trow);
+        const int off = trow * DH + ch * 8 + (li & 1) * 4;
+        d_ = __builtin_shufflevector(lds_read_tr4(sO + off), lds_read_tr4(sO + off + 16 * DH), 0, 1, 2, 3, 4, 5, 6, 7);
+        q_ = __builtin_shufflevector(lds_read_tr4(sQ + off), lds_read_tr4(sQ + off + 16 * DH), 0, 1, 2, 3, 4, 5, 6, 7);
+      };
+      tr_read(0, dot[0], qtf[0]);
+#pragma unroll
+      for (int db = 0; db < DB; ++db) {
+        const int cur = db & 1;
+        if (db + 1 < DB) tr_read(db + 1, dot[cur ^ 1], qtf[cur ^ 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (2 * k2c < nvq_c) {
+#pragma unroll
+          for (int cb = 0; cb < CBK; ++cb) {
+            dv[cb][db] = mfma16(dot[cur], pf[cb], dv[cb][db]);
+            dk[cb][db] = mfma16(qtf[cur], dsf[cb], dk[cb][db]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if constexpr (DO_A) {
+      const bf16_t* sQ = sA;
+      const bf16_t* sO = sA + TILE_E;
+      bf16x8 qfr[2], dofr[2];
+      auto row_read = [&](int st, bf16x8& q_, bf16x8& d_) {
+        const int row = k2a * 32 + (st / KS) * 16 + li, ks = st % KS;
+        const int ch = (ks * 4 + g) ^ dkv_swz<DH>(row);
+        q_ = lds_read8(sQ + row * DH + ch * 8);
+        d_ = lds_read8(sO + row * DH + ch * 8);
+      };
+      row_read(0, qfr[0], dofr[0]);
+#pragma unroll
+      for (int st = 0; st < 2 * KS; ++st) {
+        const int q2 = st / KS, ks = st % KS, cur = st & 1;
+        if (st + 1 < 2 * KS) row_read(st + 1, qfr[cur ^ 1], dofr[cur ^ 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (2 * k2a + q2 < nvq_a) {
+#pragma unroll
+          for (int cb = 0; cb < CBK; ++cb) {
+            s[cb][q2] = (ks == 0) ? mfma16(qfr[cur], kf[cb][0], f32x4{0.f, 0.f, 0.f, 0.f}) : mfma16(qfr[cur], kf[cb][ks], s[cb][q2]);
+            dp[cb][q2] = (ks == 0) ? mfma16(dofr[cur], vf[cb][0], f32x4{0.f, 0.f, 0.f, 0.f}) : mfma16(dofr[cur], vf[cb][ks], dp[cb][q2]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+  // ---- Y: P, dS of half-tile (q0, k2) out of its stage's lse / delta
+  auto seg_y = [&](const bf16_t* __restrict__ st_, int q0, int k2, int nvq, bool masked) {
+    if (idle) return;
+    const float* sL = reinterpret_cast<const float*>(st_ + 2 * TILE_E);
+    const float* sD = sL + KVT;
+#pragma unroll
+    for (int q2 = 0; q2 < 2; ++q2) {
+      const int qb = 2 * k2 + q2;
+      if (qb >= nvq) {
+#pragma unroll
+        for (int cb = 0; cb < CBK; ++cb) {
+          s[cb][q2] = f32x4{0.f, 0.f, 0.f, 0.f};
+          dp[cb][q2] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        continue;
+      }
+      const f32x4 l4 = *reinterpret_cast<const f32x4*>(sL + qb * 16 + 4 * g) * LOG2E;
+      const f32x4 d4 = *reinterpret_cast<const f32x4*>(sD + qb * 16 + 4 * g);
+#pragma unroll
+      for (int cb = 0; cb < CBK; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float p = __builtin_amdgcn_exp2f(fmaf(s[cb][q2][r], c, -l4[r]));
+          if (masked && (q0 * KVT + qb * 16 + 4 * g + r >= len)) p = 0.f;
+          s[cb][q2][r] = p;
+          dp[cb][q2][r] = p * (dp[cb][q2][r] - d4[r]);
+        }
+    }
+#pragma unroll
+    for (int cb = 0; cb < CBK; ++cb) {
+      pf[cb] = pack8(s[cb][0], s[cb][1]);
+      dsf[cb] = pack8(dp[cb][0], dp[cb][1]);
+    }
+  };
+  auto stage_of = [&](int t) { return base + (t % 3) * STAGE; };
+  auto nvq_of = [&](int t) { return t == nqt - 1 ? nvq_last : KVT / 16; };
+  // ---- prologue: query tiles 0 and 1
+  fetch(0, stage_of(0));
+  if (nqt > 1) fetch(1, stage_of(1));
+  __builtin_amdgcn_s_waitcnt(0x0070);   // (the builtin: hipcc must know that the K / V fragment loads have landed -- attn_fwd_pair_kernel)
+  asm volatile("s_barrier" ::: "memory");
+  if (h == 1) asm volatile("s_barrier" ::: "memory");   // half B runs one segment behind
+  seg_x(base, 0, 0, stage_of(0), 0, nvq_of(0), std::false_type{}, std::true_type{});   // X_0: A(0)
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  // (two half-tiles per trip, k2 a compile-time constant in every segment body)
+  auto step = [&](int t, auto k2_tag) {
+    constexpr int k2 = decltype(k2_tag)::value;
+    const int hh = 2 * t + k2;
+    // Y_hh: the refill first (query tile t + 2 over tile t - 1, whose last reader was X_2t), then the exponentials
+    if (k2 == 0 && t + 2 < nqt) fetch(t + 2, stage_of(t + 2));
+    __builtin_amdgcn_sched_barrier(0);
+    seg_y(stage_of(t), t, k2, nvq_of(t), t == nqt - 1);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // X_{hh+1}: C(hh), then A(hh + 1)
+    if (hh + 1 < NH) {
+      const int tn = (hh + 1) >> 1;
+      seg_x(stage_of(t), k2, nvq_of(t), stage_of(tn), 1 - k2, nvq_of(tn), std::true_type{}, std::true_type{});
+    } else {
+      seg_x(stage_of(t), k2, nvq_of(t), base, 0, 0, std::true_type{}, std::false_type{});
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+#pragma clang loop unroll(disable)
+  for (int t = 0; t < nqt; ++t) {
+    step(t, std::integral_constant<int, 0>{});
+    step(t, std::integral_constant<int, 1>{});
+  }
+  if (h == 0) asm volatile("s_barrier" ::: "memory");   // half A's trailing segment
+#pragma unroll
+  for (int cb = 0; cb < CBK; ++cb) {
+    bf16_t* drow = dqkv + (size_t)(seq0 + min(krow[cb], len - 1)) * ld + h * DH;
+    store_row_blocks<DB>(drow + D, krow[cb] < len, dk[cb], scale, g);
+    store_row_blocks<DB>(drow + 2 * D, krow[cb] < len, dv[cb], 1.0f, g);
+  }
+}
+#endif  // CHADA_AB_SWITCHES
+
 // =====================================================================================
 // backward dQ, LDS-DMA variant (dh = 96; dh = 192 with one query block per wave): the K / V tiles go global -> LDS by LDS-DMA into two row-major stages swizzled on
 // the source side (dkv_swz: K is read both row-wise and transposed), one barrier per key tile, no staging registers; LDS
@@ -2137,8 +2356,15 @@ static int attn_bwd_launch(const chada_bf16* qkv_, const chada_bf16* out_, const
         hipLaunchKernelGGL((attn_bwd_dq_dma_kernel<96, 2, true>), dim3(n_work * H), blk, 0, s, qkv, dout, lse, delta, dqkv, cu_seqlens, work, T, D, H, scale, out);
       else if (parts & 2)
         hipLaunchKernelGGL((attn_bwd_dq_dma_kernel<96, 2, false>), dim3(n_work * H), blk, 0, s, qkv, dout, lse, delta, dqkv, cu_seqlens, work, T, D, H, scale, out);
-      if (parts & 4)
+      if (parts & 4) {
+#if CHADA_AB_SWITCHES
+        static const int dkv_pair = getenv("CHADAVIT_ATTN_DKV_PAIR") ? atoi(getenv("CHADAVIT_ATTN_DKV_PAIR")) : 0;
+        if (dkv_pair > 0 && H == 2)
+          hipLaunchKernelGGL((attn_bwd_dkv_pair_kernel<96>), dim3(n_work), dim3(512), 0, s, qkv, dout, lse, delta, dqkv, cu_seqlens, work, T, D, scale);
+        else
+#endif
         hipLaunchKernelGGL((attn_bwd_dkv_dma_kernel<96, 2>), dim3(n_work * H), blk, 0, s, qkv, dout, lse, delta, dqkv, cu_seqlens, work, T, D, H, scale);
+      }
       break;
     case 192:  // one query block per wave in dQ: with two, Q + dO + dQ spill (65-124 VGPRs)
       if ((parts & 2) && fuse_delta)
