@@ -384,7 +384,7 @@ def test_attention_fwd_row_major_stages_and_paired_schedule_are_bit_identical_to
     instruction, chunks XOR-swizzled on the source side); a side build with the fragment-major records of rounds 3-5 (-DCHADA_M32_RM=0) must give the
     same outputs and LSE BIT FOR BIT on ragged batches at dh 96 / 192 incl. the lean softmax's re-run (a spiked score), single-tile and edge-length
     sequences.  (b) The paired (ping-pong) forward -- two heads per 512-thread block, the halves one segment apart; built, measured, not adopted: a
-    side-build kernel, variant 6 of chadavit_attn_fwd_m32 -- must reproduce the unpaired kernel bit for bit, re-run included."""
+    side-build kernel, variant 6 of chadavit_attn_fwd_m32 -- must reproduce the unpaired kernel bit for bit, re-run included; (c) likewise the paired dK/dV kernel at dh 96."""
     import subprocess, sys, os
     from chadavit_amd.build import build, build_ab
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -402,6 +402,13 @@ def test_attention_fwd_row_major_stages_and_paired_schedule_are_bit_identical_to
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if "identical=" in ln]
     assert len(lines) == 18 and all("identical=True" in ln for ln in lines), [ln for ln in lines if "identical=True" not in ln]
+    # (c) the paired dK/dV at dh 96 (side-build kernel, CHADAVIT_ATTN_DKV_PAIR=1: built, register-bound, not adopted) reproduces the product's dqkv and delta
+    dumps = []
+    for env in (dict(os.environ), dict(os.environ, CHADAVIT_HIP_LIB=build_ab(), CHADAVIT_ALLOW_FOREIGN_LIB="1", CHADAVIT_ATTN_DKV_PAIR="1")):
+        r = subprocess.run([sys.executable, os.path.join(root, "scratch", "r6", "bwd_dump.py")], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        dumps.append([ln for ln in r.stdout.splitlines() if ln and ln[0].isdigit()])
+    assert len(dumps[0]) == 12 and dumps[0] == dumps[1], [(a, b) for a, b in zip(*dumps) if a != b][:4]
 
 
 def test_attention_fwd_row_major_stages():
