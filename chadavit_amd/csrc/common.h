@@ -145,6 +145,16 @@ __device__ __forceinline__ float row16_max(float v) {
 __device__ __forceinline__ float wave_sum(float v) { return rows_sum(row16_sum(v)); }
 __device__ __forceinline__ float wave_max(float v) { return rows_max(row16_max(v)); }
 
+// ReLU as ONE instruction on an MFMA result: fmaxf(x, 0.f) compiles to two v_max_f32 -- hipcc first canonicalises the accumulator register
+// (v_max_f32 x, x, x: it cannot know an MFMA output is not a signalling NaN), then takes the maximum; in the block kernels that was 16 of the 83 vector
+// instructions of an FFN chunk (round 6).  The integer maximum of the bit pattern against 0 is the same function for every non-NaN input (positive floats
+// are positive integers, negative floats and -0 negative ones) and returns +0 for them; a NaN with the sign bit clear passes through (torch.relu's
+// behaviour -- fmaxf dropped it), one with the sign bit set becomes 0.
+__device__ __forceinline__ float relu_f(float x) {
+  const int b = __builtin_bit_cast(int, x);
+  return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
+
 __device__ __forceinline__ float bf2f(bf16_t v) { return (float)v; }
 __device__ __forceinline__ bf16_t f2bf(float v) { return (bf16_t)v; }
 

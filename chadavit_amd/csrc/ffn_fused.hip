@@ -317,8 +317,8 @@ __device__ __forceinline__ void ffn_core(BufRsrc wrs, unsigned blk_bytes, bf16_t
           hb[rt][r] = (bf16_t)relu_select(hacc[rt][0][r], rbits, rt * 8 + r);
           hb[rt][4 + r] = (bf16_t)relu_select(hacc[rt][1][r], rbits, rt * 8 + 4 + r);
         } else {
-          hb[rt][r] = (bf16_t)fmaxf(hacc[rt][0][r], 0.f);
-          hb[rt][4 + r] = (bf16_t)fmaxf(hacc[rt][1][r], 0.f);
+          hb[rt][r] = (bf16_t)relu_f(hacc[rt][0][r]);
+          hb[rt][4 + r] = (bf16_t)relu_f(hacc[rt][1][r]);
         }
       }
       // "> 0" on the bf16 values the backward would otherwise read back from H: they left a ReLU, so "!= 0" (sign masked off for a

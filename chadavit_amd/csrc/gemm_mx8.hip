@@ -303,7 +303,7 @@ __global__ __launch_bounds__((MX_NCONS + MX_NPROD) * 64, 3) void gemm_mx8_kernel
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             x[nt][i] = acc[nt][mt][i] + bia[nt][i];
-            if constexpr (EPI == MXE_RELU) x[nt][i] = fmaxf(x[nt][i], 0.f);
+            if constexpr (EPI == MXE_RELU) x[nt][i] = relu_f(x[nt][i]);
           }
           acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
         }

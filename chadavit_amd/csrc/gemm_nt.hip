@@ -67,7 +67,7 @@ __device__ __forceinline__ void epi_store(const NtArgs& a, f32x4 v0, f32x4 v1, f
   int orow = m;
   if constexpr (EPI == EPI_RELU) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { v0[r] = fmaxf(v0[r], 0.f); v1[r] = fmaxf(v1[r], 0.f); }
+    for (int r = 0; r < 4; ++r) { v0[r] = relu_f(v0[r]); v1[r] = relu_f(v1[r]); }
   } else if constexpr (EPI == EPI_GELU) {
     bf16x8 pre;
 #pragma unroll
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_smallk_kernel(NtArgs a, int n_
           v1 += *reinterpret_cast<const f32x4*>(sBias + (n0 - nbeg) + ch * 8 + 4);
           if constexpr (EPI == EPI_RELU) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { v0[r] = fmaxf(v0[r], 0.f); v1[r] = fmaxf(v1[r], 0.f); }
+            for (int r = 0; r < 4; ++r) { v0[r] = relu_f(v0[r]); v1[r] = relu_f(v1[r]); }
           } else if constexpr (EPI == EPI_GELU) {
             const int m = min(m0 + mb * 16 + row, M - 1);
             bf16x8 pre;
