@@ -110,6 +110,54 @@ struct Cfg {
   static_assert(TILE % QPB == 0, "a work item is a whole number of blocks");
 };
 
+// Record r of a K / V tile as lane l fetches it: the key row inside the tile and the element offset of the lane's 16 bytes inside a token row of qkv
+// (K section at D, V section at 2 D; this head's columns start at the resource's base).
+template <int DH, int CB, int NW>
+__device__ __forceinline__ void m32_rec_of(int r, int l, int D, int& row, unsigned& col) {
+  using C = Cfg<DH, CB, NW>;
+  constexpr int KS = C::KS, DB = C::DB, NKR = C::NKR;
+  const int li = l & 31, hi = l >> 5;
+  if (CHADA_M32_RM) {   // piece r = 64 consecutive 16-byte chunks of the row-major K (r < NKR) / V image; source chunk un-swizzled
+    static_assert(!CHADA_M32_RM || C::NVR == NKR, "row-major stages: K and V tiles of equal size");
+    const int id = (r % NKR) * 64 + l, ch = id % (DH / 8);
+    row = id / (DH / 8);
+    col = (r < NKR ? D : 2 * D) + (ch ^ rm_swz<DH>(row)) * 8;
+  } else if (r < NKR) {
+    row = (r / KS) * 32 + li;
+    col = D + (r % KS) * 16 + hi * 8;
+  } else {
+    const int rv = r - NKR;
+    row = (rv / DB) * 16 + (l >> 2);
+    col = 2 * D + (rv % DB) * 32 + (l & 3) * 8;
+  }
+}
+// The wave's LDS-DMA instructions for the key tile that starts at row `first`.  A tile that lies wholly inside the sequence -- every tile but the last --
+// needs no per-lane arithmetic at all: the lane's byte offset inside the tile is a constant (`lane_off`, one register per piece) and the tile's start rides
+// in the instruction's scalar offset.  (Round 6: computed per piece -- add, clamp, 32-bit multiply, add -- it was 46 of the loop's ~160 vector instructions.)
+// Only the sequence's last tile clamps its rows, and recomputes the records for that.
+template <int DH, int CB, int NW>
+__device__ __forceinline__ void m32_issue_tile(BufRsrc qb, bf16_t* __restrict__ dst, int first, int len, unsigned ldu, int D, int w, int l,
+                                               const unsigned (&lane_off)[Cfg<DH, CB, NW>::NRW]) {
+  using C = Cfg<DH, CB, NW>;
+  constexpr int NRW = C::NRW, KVT = C::KVT;
+  if (first + KVT <= len) {
+    const unsigned tile_bytes = (unsigned)first * ldu * 2u;
+#pragma unroll
+    for (int i = 0; i < NRW; ++i) lds_dma16(qb, dst + (w + NW * i) * 512, lane_off[i], tile_bytes);
+  } else {
+    int lx = l;
+    asm volatile("" : "+v"(lx));   // (recomputed here, once per work item, instead of living in registers across the tile loop)
+#pragma unroll
+    for (int i = 0; i < NRW; ++i) {
+      int row;
+      unsigned col;
+      m32_rec_of<DH, CB, NW>(w + NW * i, lx, D, row, col);
+      const unsigned off = (unsigned)min(first + row, len - 1) * ldu + col;
+      lds_dma16(qb, dst + (w + NW * i) * 512, off * 2, 0);
+    }
+  }
+}
+
 struct WorkItem { int b, t, h, part; };
 template <int SPLIT>
 __device__ __forceinline__ WorkItem decode_work(const int* __restrict__ work, int H) {
@@ -134,19 +182,13 @@ __device__ __forceinline__ WorkItem decode_work(const int* __restrict__ work, in
 #endif
 template <int DH, int CB, int NW, int MODE, bool MASKED>
 __device__ __forceinline__ void fwd_tile(BufRsrc qb, bf16_t* __restrict__ dst, const bf16_t* __restrict__ sK, bool issue, int kt, int len,
-                                         int qrow0, unsigned ldu, float c, int w, int l, const int (&rec_row)[Cfg<DH, CB, NW>::NRW],
-                                         const unsigned (&rec_col)[Cfg<DH, CB, NW>::NRW], const bf16x8 (&qf)[CB][Cfg<DH, CB, NW>::KS],
+                                         int qrow0, unsigned ldu, float c, int w, int l, int D,
+                                         const unsigned (&lane_off)[Cfg<DH, CB, NW>::NRW], const bf16x8 (&qf)[CB][Cfg<DH, CB, NW>::KS],
                                          f32x16 (&o)[CB][Cfg<DH, CB, NW>::DB], float (&m)[CB], float (&ls)[CB], f32x16 (&minit)[CB]) {
   using C = Cfg<DH, CB, NW>;
-  constexpr int KS = C::KS, DB = C::DB, KB = C::KB, KP = C::KP, KVT = C::KVT, NKR = C::NKR, NRW = C::NRW;
+  constexpr int KS = C::KS, DB = C::DB, KB = C::KB, KP = C::KP, KVT = C::KVT, NKR = C::NKR;
   const int hi = l >> 5;
-  if (issue && (CHADA_M32_ABL & 1) == 0) {
-#pragma unroll
-    for (int i = 0; i < NRW; ++i) {
-      const unsigned off = (unsigned)min(((CHADA_M32_ABL & 32) ? 0 : (kt + 1) * KVT) + rec_row[i], len - 1) * ldu + rec_col[i];
-      lds_dma16(qb, dst + (w + NW * i) * 512, off * 2, 0);
-    }
-  }
+  if (issue && (CHADA_M32_ABL & 1) == 0) m32_issue_tile<DH, CB, NW>(qb, dst, (CHADA_M32_ABL & 32) ? 0 : (kt + 1) * KVT, len, ldu, D, w, l, lane_off);
   __builtin_amdgcn_sched_barrier(0);  // the DMA goes out first (see attention.hip / DESIGN 3a)
   if (qrow0 >= len) return;           // (wave-uniform) no query row of this wave exists: it only feeds the DMA and the barriers
   const bf16_t* sV = sK + NKR * 512;
@@ -290,11 +332,11 @@ __device__ __forceinline__ void fwd_tile(BufRsrc qb, bf16_t* __restrict__ dst, c
                                 else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); } while (0)
 template <int DH, int CB, int NW, int LEAN>
 __device__ __forceinline__ void fwd_item(BufRsrc qrs, bf16_t* smem, int len, int qrow0, unsigned ldu, float c, int w, int l,
-                                         const int (&rec_row)[Cfg<DH, CB, NW>::NRW], const unsigned (&rec_col)[Cfg<DH, CB, NW>::NRW],
+                                         int D, const unsigned (&lane_off)[Cfg<DH, CB, NW>::NRW],
                                          const bf16x8 (&qf)[CB][Cfg<DH, CB, NW>::KS], f32x16 (&o)[CB][Cfg<DH, CB, NW>::DB], float (&m)[CB],
                                          float (&ls)[CB]) {
   using C = Cfg<DH, CB, NW>;
-  constexpr int KVT = C::KVT, NRW = C::NRW, STAGE = C::STAGE, DB = C::DB;
+  constexpr int KVT = C::KVT, STAGE = C::STAGE, DB = C::DB;
   f32x16 minit[CB];
 #pragma unroll
   for (int cb = 0; cb < CB; ++cb) {
@@ -306,29 +348,25 @@ __device__ __forceinline__ void fwd_item(BufRsrc qrs, bf16_t* smem, int len, int
   }
   const int nkt = (len + KVT - 1) / KVT;
   // tile 0: no LDS read follows before the first barrier, issued bare
-#pragma unroll
-  for (int i = 0; i < NRW; ++i) {
-    const unsigned off = (unsigned)min(rec_row[i], len - 1) * ldu + rec_col[i];
-    lds_dma16(qrs, smem + (w + NW * i) * 512, off * 2, 0);
-  }
+  m32_issue_tile<DH, CB, NW>(qrs, smem, 0, len, ldu, D, w, l, lane_off);
   constexpr int M_FIRST = LEAN ? 1 : 0, M_REST = LEAN == 1 ? 2 : (LEAN == 2 ? 4 : 0);
   if (nkt == 1) {
     M32_TILE_BARRIER();
-    fwd_tile<DH, CB, NW, M_FIRST, true>(qrs, smem + STAGE, smem, false, 0, len, qrow0, ldu, c, w, l, rec_row, rec_col, qf, o, m, ls, minit);
+    fwd_tile<DH, CB, NW, M_FIRST, true>(qrs, smem + STAGE, smem, false, 0, len, qrow0, ldu, c, w, l, D, lane_off, qf, o, m, ls, minit);
     return;
   }
   M32_TILE_BARRIER();
-  fwd_tile<DH, CB, NW, M_FIRST, false>(qrs, smem + STAGE, smem, true, 0, len, qrow0, ldu, c, w, l, rec_row, rec_col, qf, o, m, ls, minit);
+  fwd_tile<DH, CB, NW, M_FIRST, false>(qrs, smem + STAGE, smem, true, 0, len, qrow0, ldu, c, w, l, D, lane_off, qf, o, m, ls, minit);
   for (int kt = 1; kt < nkt - 1; ++kt) {
     // tile kt has landed (LDS-DMA completion is visible only through the issuing wave's vmcnt) and everybody is done reading
     // the other stage
     M32_TILE_BARRIER();
-    fwd_tile<DH, CB, NW, M_REST, false>(qrs, smem + ((kt + 1) & 1) * STAGE, smem + (kt & 1) * STAGE, true, kt, len, qrow0, ldu, c, w, l, rec_row,
-                                        rec_col, qf, o, m, ls, minit);
+    fwd_tile<DH, CB, NW, M_REST, false>(qrs, smem + ((kt + 1) & 1) * STAGE, smem + (kt & 1) * STAGE, true, kt, len, qrow0, ldu, c, w, l, D,
+                                        lane_off, qf, o, m, ls, minit);
   }
   M32_TILE_BARRIER();
   fwd_tile<DH, CB, NW, M_REST, true>(qrs, smem + (nkt & 1) * STAGE, smem + ((nkt - 1) & 1) * STAGE, false, nkt - 1, len, qrow0, ldu, c, w, l,
-                                     rec_row, rec_col, qf, o, m, ls, minit);
+                                     D, lane_off, qf, o, m, ls, minit);
 }
 
 template <int DH, int CB, int NW, int LEAN>
@@ -337,7 +375,7 @@ __global__ __launch_bounds__(64 * NW, (CB > 1 ? 1 : (DH <= 96 ? (KV32_AT_DH96 ? 
                                                                                     const int* __restrict__ work, int T, int D, int H,
                                                                                     float scale) {
   using C = Cfg<DH, CB, NW>;
-  constexpr int KS = C::KS, DB = C::DB, NKR = C::NKR, NRW = C::NRW, STAGE = C::STAGE, QPB = C::QPB;
+  constexpr int KS = C::KS, DB = C::DB, NRW = C::NRW, STAGE = C::STAGE, QPB = C::QPB;
   __shared__ __attribute__((aligned(16))) bf16_t smem[2 * STAGE];
 
   const int tid = threadIdx.x, l = tid & 63, hi = l >> 5, li = l & 31;
@@ -369,25 +407,14 @@ __global__ __launch_bounds__(64 * NW, (CB > 1 ? 1 : (DH <= 96 ? (KV32_AT_DH96 ? 
       qf[cb][ks] = v;
     }
   }
-  // record r of a tile is fetched by wave r % NW (instruction r / NW of that wave)
-  int rec_row[NRW];
-  unsigned rec_col[NRW];
+  // record r of a tile is fetched by wave r % NW (instruction r / NW of that wave): the lane's byte offset inside a tile
+  unsigned lane_off[NRW];
 #pragma unroll
   for (int i = 0; i < NRW; ++i) {
-    const int r = w + NW * i;
-    if (CHADA_M32_RM) {   // piece r = 64 consecutive 16-byte chunks of the row-major K (r < NKR) / V image; source chunk un-swizzled
-      static_assert(!CHADA_M32_RM || C::NVR == NKR, "row-major stages: K and V tiles of equal size");
-      const int id = (r % NKR) * 64 + l, row = id / (DH / 8), ch = id % (DH / 8);
-      rec_row[i] = row;
-      rec_col[i] = (r < NKR ? D : 2 * D) + (ch ^ rm_swz<DH>(row)) * 8;
-    } else if (r < NKR) {
-      rec_row[i] = (r / KS) * 32 + li;
-      rec_col[i] = D + (r % KS) * 16 + hi * 8;
-    } else {
-      const int rv = r - NKR;
-      rec_row[i] = (rv / DB) * 16 + (l >> 2);
-      rec_col[i] = 2 * D + (rv % DB) * 32 + (l & 3) * 8;
-    }
+    int row;
+    unsigned col;
+    m32_rec_of<DH, CB, NW>(w + NW * i, l, D, row, col);
+    lane_off[i] = ((unsigned)row * 3u * (unsigned)D + col) * 2u;
   }
   const unsigned ldu = 3u * (unsigned)D;
   const int qrow0 = qt * TILE + part * QPB + w * 32 * CB;  // first query row of this wave
@@ -395,7 +422,7 @@ __global__ __launch_bounds__(64 * NW, (CB > 1 ? 1 : (DH <= 96 ? (KV32_AT_DH96 ? 
 
   f32x16 o[CB][DB];
   float m[CB], ls[CB], lt[CB];
-  fwd_item<DH, CB, NW, LEAN>(qrs, smem, len, qrow0, ldu, LEAN == 1 ? 1.0f : c, w, l, rec_row, rec_col, qf, o, m, ls);
+  fwd_item<DH, CB, NW, LEAN>(qrs, smem, len, qrow0, ldu, LEAN == 1 ? 1.0f : c, w, l, D, lane_off, qf, o, m, ls);
   bool bad = false;
 #pragma unroll
   for (int cb = 0; cb < CB; ++cb) {
@@ -416,7 +443,7 @@ __global__ __launch_bounds__(64 * NW, (CB > 1 ? 1 : (DH <= 96 ? (KV32_AT_DH96 ? 
     for (int i = 0; i < NW; ++i) any |= flags[i];
     if (any) {
       __syncthreads();  // everybody has read the flags before the re-run's first DMA may land on them
-      fwd_item<DH, CB, NW, 0>(qrs, smem, len, qrow0, ldu, LEAN == 1 ? 1.0f : c, w, l, rec_row, rec_col, qf, o, m, ls);
+      fwd_item<DH, CB, NW, 0>(qrs, smem, len, qrow0, ldu, LEAN == 1 ? 1.0f : c, w, l, D, lane_off, qf, o, m, ls);
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb) lt[cb] = half_sum(ls[cb]);
     }

@@ -1,0 +1,10 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+S=scratch/sidebuild; O=gpurun_out/r6_run12; mkdir -p $O
+python scratch/r6/fwd_dump.py 2>/dev/null > $O/new.txt
+CHADAVIT_ALLOW_FOREIGN_LIB=1 CHADAVIT_HIP_LIB=$S/oldfwd/libchadavit_hip_oldfwd.so python scratch/r6/fwd_dump.py 2>/dev/null > $O/old.txt
+echo "== identity (empty diff = bit-identical)"; diff $O/new.txt $O/old.txt | head -5; wc -l $O/new.txt
+for i in 1 2; do
+echo "== new (tile start in the scalar offset)"; python scratch/r6/p32_time.py 2>&1 | grep -v amdgpu.ids | cut -c1-100
+echo "== old"; CHADAVIT_ALLOW_FOREIGN_LIB=1 CHADAVIT_HIP_LIB=$S/oldfwd/libchadavit_hip_oldfwd.so python scratch/r6/p32_time.py 2>&1 | grep -v amdgpu.ids | cut -c1-100
+done
