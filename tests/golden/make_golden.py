@@ -220,6 +220,8 @@ def golden_traj(name, D, PR, nch, sizes, n_large, steps=5, lr=5e-4, wd=1e-4, bas
     epoch 0: dino.py:367-376).  BASELINE configs[0] shape by default: Tiny, one-channel images, two global crops.  `steps` consecutive steps
     of the unmodified reference, a NEW procedural batch every step (seed 7 + k), epoch = k // steps_per_epoch, Lightning's hook order
     (training_step, backward, on_after_backward, optimizer.step, optimizer_zero_grad, on_train_batch_end's two updates)."""
+    per_step = isinstance(nch[0], (list, tuple))   # a different channel mix every step (the ragged packer's description changes from step to step)
+    nch_of = (lambda k: list(nch[k])) if per_step else (lambda k: list(nch))
     cfg = refshim.dino_cfg(embed_dim=D, num_prototypes=PR, num_large_crops=n_large, num_small_crops=len(sizes) - n_large, lr=lr,
                            weight_decay=wd, base_tau=base_tau)
     model = ref.DINO(cfg)
@@ -229,7 +231,7 @@ def golden_traj(name, D, PR, nch, sizes, n_large, steps=5, lr=5e-4, wd=1e-4, bas
         g["params"] = list(g["params"])
     opt = torch.optim.AdamW(params, lr=lr, weight_decay=wd)
     named = dict(model.named_parameters())
-    out = {"D": D, "P": PR, "nch": np.asarray(nch), "sizes": np.asarray(sizes), "n_large": n_large, "steps": steps, "lr": lr, "wd": wd,
+    out = {"D": D, "P": PR, "nch": np.asarray(nch), "nch_per_step": int(per_step), "sizes": np.asarray(sizes), "n_large": n_large, "steps": steps, "lr": lr, "wd": wd,
            "base_tau": base_tau, "max_steps": max_steps, "steps_per_epoch": steps_per_epoch, "param_names": np.asarray(TRAJ_PARAMS)}
     rec = {k: [] for k in ("loss", "epoch", "teacher_temp", "center", "center_sum", "tau_used", "tau_next", "momentum_z_rowsum", "momentum_z_rowsq",
                            "z_rowsum", "z_rowsq", "student_sums", "teacher_sums", "student_sq", "teacher_sq", "grad_norm_total")}
@@ -238,7 +240,7 @@ def golden_traj(name, D, PR, nch, sizes, n_large, steps=5, lr=5e-4, wd=1e-4, bas
         model.current_epoch = epoch
         if k % steps_per_epoch == 0:
             model.on_train_epoch_start()
-        imgs = P.make_images(nch, sizes, seed=7 + k)
+        imgs = P.make_images(nch_of(k), sizes, seed=7 + k)
         batch = ref.one_channel_collate_fn([(i, c, l) for i, (c, l) in enumerate(imgs)])
         seen = {"head": [], "momentum_head": []}
         hooks = [getattr(model, m).register_forward_hook(lambda m_, i_, o_, m=m: seen[m].append(o_.detach().clone())) for m in seen]
@@ -658,7 +660,13 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "traj":
         # round 6: five consecutive steps on BASELINE configs[0]'s shape (Tiny, four one-channel images, two global crops), the epoch
         # boundary after step 3 (teacher temperature 0.04 -> 0.055, the last layer thawed)
-        golden_traj("traj_tiny_c1", 192, 4096, [1, 1, 1, 1], [224, 224], 2)
+        which = sys.argv[2:] or ["c1", "mixed"]
+        if "c1" in which:
+            golden_traj("traj_tiny_c1", 192, 4096, [1, 1, 1, 1], [224, 224], 2)
+        if "mixed" in which:
+            # ... and with what the path is FOR: a different 1-10 channel mix every step, two global + two local crops (the ragged descriptions, the
+            # bicubic position rows of the 96-pixel crops and the channel tokens' gradient slots change from step to step)
+            golden_traj("traj_tiny_mixed_multicrop", 192, 4096, [[3, 1, 5], [2, 7, 1], [1, 1, 10], [4, 2, 3], [6, 1, 2]], [224, 224, 96, 96], 2)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "attnmap":
         golden_attnmap("attnmap_tiny", 192, 2, 224, 51, 52)

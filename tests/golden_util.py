@@ -152,6 +152,12 @@ def grad_subsets_vs_golden(named, g, cos_min=0.99, norm_rel=6e-2):
     return worst
 
 
+def traj_channels(g):
+    """step -> the channel counts of that step's images (a trajectory golden holds one mix for all steps or one per step)."""
+    per_step = "nch_per_step" in g.files and int(g["nch_per_step"])
+    return (lambda k: [int(c) for c in g["nch"][k]]) if per_step else (lambda k: [int(c) for c in g["nch"]])
+
+
 def oracle_trajectory(g):
     """Consecutive training steps of the CPU oracle on a trajectory golden's schedule (tests/golden/make_golden.py::golden_traj): a new
     procedural batch every step (seed 7 + k), epoch = k // steps_per_epoch (teacher temperature, last layer frozen during epoch 0), AdamW as
@@ -161,7 +167,8 @@ def oracle_trajectory(g):
     import torch
     from oracle import chada_ref as R
     D, PR = int(g["D"]), int(g["P"])
-    nch, sizes = [int(c) for c in g["nch"]], [int(s) for s in g["sizes"]]
+    sizes = [int(s) for s in g["sizes"]]
+    nch_of = traj_channels(g)
     lr, wd, tau, max_steps, spe = float(g["lr"]), float(g["wd"]), float(g["base_tau"]), int(g["max_steps"]), int(g["steps_per_epoch"])
     names = [str(n) for n in g["param_names"]]
     sd = build_sd(D, PR)
@@ -170,7 +177,7 @@ def oracle_trajectory(g):
     recs = []
     for k in range(int(g["steps"])):
         epoch = k // spe
-        crops, _, ncl = R.collate(P.make_images(nch, sizes, seed=7 + k))
+        crops, _, ncl = R.collate(P.make_images(nch_of(k), sizes, seed=7 + k))
         loss, grads, newc, aux = R.training_step(sd, crops, ncl, int(g["n_large"]), float(temps[epoch]), freeze_last_layer=epoch < 1)
         tot = sum(float(v.double().norm()) ** 2 for v in grads.values() if v is not None) ** 0.5
         for n, gr in grads.items():

@@ -1229,8 +1229,9 @@ def test_two_steps_run_and_loss_moves():
     assert "dino_loss_func.center" in sd and "momentum_head.last_layer.weight_v" in sd and "backbone.blocks.11.norm2.bias" in sd
 
 
-@pytest.mark.parametrize("mode", ["eager", "graph"])
-def test_five_step_trajectory_vs_golden(mode):
+@pytest.mark.parametrize("name,mode", [("traj_tiny_c1", "eager"), ("traj_tiny_c1", "graph"), ("traj_tiny_mixed_multicrop", "eager"),
+                                       ("traj_tiny_mixed_multicrop", "graph")])
+def test_five_step_trajectory_vs_golden(name, mode):
     """Round 6: state carried between steps.  Golden traj_tiny_c1 = five consecutive steps of the unmodified reference (BASELINE configs[0]'s
     shape: Tiny, four one-channel images, two global crops; a new batch every step; the epoch boundary after step 3 moves the teacher
     temperature and thaws the last layer).  The HIP path through the hook loop (Trainer.train_step) and through the whole-step hipGraph
@@ -1242,9 +1243,10 @@ def test_five_step_trajectory_vs_golden(mode):
     from chadavit_amd.methods.dino import DINO
     from chadavit_amd.trainer import Trainer
     dev = _dev()
-    g = np.load(os.path.join(GOLDEN, "traj_tiny_c1.npz"))
+    from tests.golden_util import traj_channels
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))   # (traj_tiny_mixed_multicrop: another 1-10 channel mix every step, two global + two local crops)
     D, PR, n_large = int(g["D"]), int(g["P"]), int(g["n_large"])
-    nch, sizes = [int(c) for c in g["nch"]], [int(s) for s in g["sizes"]]
+    nch_of, sizes = traj_channels(g), [int(s) for s in g["sizes"]]
     spe = int(g["steps_per_epoch"])
     model = DINO(_cfg(D, PR, n_large, len(sizes) - n_large, lr=float(g["lr"]), wd=float(g["wd"]), base_tau=float(g["base_tau"])))
     model.load_state_dict(build_sd(D, PR))
@@ -1256,7 +1258,7 @@ def test_five_step_trajectory_vs_golden(mode):
     worst = {"loss": 0.0, "center": 0.0, "student_sq_rel": 0.0, "tz_sq_rel": 0.0}
     bad = []
     for k in range(int(g["steps"])):
-        crops, labels, ncl = one_channel_collate_fn(P.make_images(nch, sizes, seed=7 + k))
+        crops, labels, ncl = one_channel_collate_fn(P.make_images(nch_of(k), sizes, seed=7 + k))
         batch = ([c.to(dev) for c in crops], labels.to(dev), ncl)
         tr.current_epoch = k // spe
         tau_used = model.momentum_updater.cur_tau
@@ -1305,7 +1307,7 @@ def test_five_step_trajectory_vs_golden(mode):
     print("trajectory", mode, worst)
     assert not bad, bad[:8]
     if mode == "graph":
-        assert len(step.graphs) == 2   # frozen / thawed last layer
+        assert len(step.graphs) == (int(g["steps"]) if "nch_per_step" in g.files and int(g["nch_per_step"]) else 2)   # one per batch signature and frozen / thawed state
         step.close()
     named = dict(model.named_parameters())
     # element-wise on a small tensor: an entry of the student whose gradient's sign is bf16 noise sits up to 2 lr k off after step k, and the EMA

@@ -193,14 +193,15 @@ def test_training_step_matches_reference(name):
     assert abs(R.tau_schedule(1, int(g["max_steps"]), float(g["base_tau"]), 1.0) - float(g["tau_next"])) < 1e-12
 
 
-def test_five_step_trajectory_matches_reference():
+@pytest.mark.parametrize("name", ["traj_tiny_c1", "traj_tiny_mixed_multicrop"])
+def test_five_step_trajectory_matches_reference(name):
     """Round 6: the state CARRIED between steps (golden traj_tiny_c1: five consecutive steps of the unmodified reference on BASELINE
     configs[0]'s shape -- Tiny, four one-channel images, two global crops -- a new batch every step, the epoch boundary after step 3).  The
     oracle must reproduce every step to fp32 round-off: the centre of step k enters the loss of k + 1 (losses/dino.py:103-118), the EMA
     teacher of step k the teacher pass of k + 1 (momentum.py:63-87), AdamW's moments and per-parameter step counts run on (the last layer
     thaws at epoch 1: dino.py:374-376), tau follows its cosine (base.py:1270-1273)."""
     from tests.golden_util import oracle_trajectory
-    g = _load("traj_tiny_c1")
+    g = _load(name)   # (traj_tiny_mixed_multicrop: a different 1-10 channel mix every step, two global + two local crops)
     recs, sd = oracle_trajectory(g)
     assert len(recs) == int(g["steps"]) == 5
     for k, r in enumerate(recs):
